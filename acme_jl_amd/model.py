@@ -1,0 +1,125 @@
+"""DiscreteModel: the data the hot path runs on (mirror of src/ACME.jl:118-148).
+
+A ``DiscreteModel`` here is plain data: Float64 matrices (numpy, Fortran order so the
+memory layout equals Julia's column-major ``Matrix{Float64}``), one element-descriptor
+table per nonlinear sub-problem (the C-ABI replacement for the reference's closures,
+src/circuit.jl:68-86), each sub-problem's initial extrapolation origin
+(p = 0, z = init_z; src/ACME.jl:253-259) and the solver selection (the third positional
+argument of the reference constructor, src/ACME.jl:150).
+
+Running a model is not done here: see ``runner.ModelRunner`` (GPU, through the C ABI).
+"""
+from __future__ import annotations
+
+import json
+from fractions import Fraction
+
+import numpy as np
+
+from . import derive as _derive
+from .circuit import MAX_ELEM_PAR
+
+# solver selection -- names follow src/solvers.jl
+SimpleSolver = "SimpleSolver"
+HomotopySolver = "HomotopySolver{SimpleSolver}"
+CachingHomotopySolver = "HomotopySolver{CachingSolver{SimpleSolver}}"   # reference default
+SOLVER_IDS = {SimpleSolver: 0, HomotopySolver: 1, CachingHomotopySolver: 2}
+
+
+def _f(m, r, c):
+    a = np.zeros((r, c), dtype=np.float64, order="F")
+    if r and c:
+        a[:, :] = np.asarray(m, dtype=np.float64).reshape(r, c)
+    return a
+
+
+class SubProblem:
+    """One nonlinear sub-problem: matrices of src/ACME.jl:123-128 + element table."""
+
+    def __init__(self, nn, nq, np_, pexp, dq, eq, fqprev, fq, q0, init_z, table):
+        self.nn, self.nq, self.np = nn, nq, np_
+        self.pexp, self.dq, self.eq, self.fqprev, self.fq = pexp, dq, eq, fqprev, fq
+        self.q0 = np.asarray(q0, dtype=np.float64).reshape(nq)
+        self.init_z = np.asarray(init_z, dtype=np.float64).reshape(nn)
+        self.table = table  # list of dict(kind, par, nq, nn, qoff, roff)
+
+    def elem_arrays(self):
+        n = len(self.table)
+        kind = np.array([e["kind"] for e in self.table], dtype=np.int32)
+        qoff = np.array([e["qoff"] for e in self.table], dtype=np.int32)
+        roff = np.array([e["roff"] for e in self.table], dtype=np.int32)
+        par = np.zeros((max(n, 1), MAX_ELEM_PAR), dtype=np.float64)
+        for i, e in enumerate(self.table):
+            par[i, :len(e["par"])] = e["par"]
+        return kind, qoff, roff, par
+
+
+class DiscreteModel:
+    """``DiscreteModel(circ, t, Solver; decompose_nonlinearity=true)`` (src/ACME.jl:150).
+
+    ``solver`` defaults to ``HomotopySolver{SimpleSolver}``: the reference's default
+    additionally wraps a ``CachingSolver`` whose per-stream, unboundedly growing k-d tree
+    only changes Newton's start point; it is deliberately not reproduced on the GPU
+    (converged results agree within the solver tolerance).
+    """
+
+    def __init__(self, circ=None, t=None, solver=HomotopySolver, decompose_nonlinearity=True,
+                 _data=None):
+        if solver not in SOLVER_IDS:
+            raise ValueError(f"unknown solver {solver!r}")
+        self.solver = solver
+        if _data is None:
+            if isinstance(t, float):
+                t = Fraction(t)   # exact binary value, like Rational{BigInt}(t)
+            _data = _derive.derive(circ, Fraction(t), decompose_nonlinearity)
+        d = _data
+        self.nx, self.nu, self.ny = d["nx"], d["nu"], d["ny"]
+        nnt = sum(d["nns"])
+        self.nn_total = nnt
+        nx, nu, ny = self.nx, self.nu, self.ny
+        self.a, self.b, self.c = _f(d["a"], nx, nx), _f(d["b"], nx, nu), _f(d["c"], nx, nnt)
+        self.x0 = np.asarray(d["x0"], dtype=np.float64).reshape(nx)
+        self.dy, self.ey, self.fy = _f(d["dy"], ny, nx), _f(d["ey"], ny, nu), _f(d["fy"], ny, nnt)
+        self.y0 = np.asarray(d["y0"], dtype=np.float64).reshape(ny)
+        self.subs = []
+        for k in range(d["nsub"]):
+            nn, nq, np_ = d["nns"][k], d["nqs"][k], d["nps"][k]
+            self.subs.append(SubProblem(
+                nn, nq, np_, _f(d["pexps"][k], nq, np_), _f(d["dqs"][k], np_, nx),
+                _f(d["eqs"][k], np_, nu), _f(d["fqprevs"][k], np_, nnt), _f(d["fqs"][k], nq, nn),
+                d["q0s"][k], d["init_zs"][k], d["tables"][k]))
+        # mutable state (src/ACME.jl:137,145): starts at zero
+        self.x = np.zeros(nx)
+
+    # size accessors (src/ACME.jl:466-472), sub-problem index 1-based like the reference
+    def np(self, k): return self.subs[k - 1].np
+    def nq(self, k): return self.subs[k - 1].nq
+    def nn(self, k=None):
+        return self.nn_total if k is None else self.subs[k - 1].nn
+
+    # --- (de)serialisation: small JSON fixtures --------------------------------------
+    def to_dict(self):
+        def m(a): return np.asarray(a).tolist()
+        return dict(
+            solver=self.solver, nx=self.nx, nu=self.nu, ny=self.ny, nsub=len(self.subs),
+            nns=[s.nn for s in self.subs], nqs=[s.nq for s in self.subs],
+            nps=[s.np for s in self.subs],
+            a=m(self.a), b=m(self.b), c=m(self.c), x0=m(self.x0),
+            dy=m(self.dy), ey=m(self.ey), fy=m(self.fy), y0=m(self.y0),
+            pexps=[m(s.pexp) for s in self.subs], dqs=[m(s.dq) for s in self.subs],
+            eqs=[m(s.eq) for s in self.subs], fqprevs=[m(s.fqprev) for s in self.subs],
+            fqs=[m(s.fq) for s in self.subs], q0s=[m(s.q0) for s in self.subs],
+            init_zs=[m(s.init_z) for s in self.subs], tables=[s.table for s in self.subs])
+
+    @classmethod
+    def from_dict(cls, d, solver=None):
+        return cls(solver=solver or d.get("solver", HomotopySolver), _data=d)
+
+    def save(self, path):
+        with open(path, "w") as fh:
+            json.dump(self.to_dict(), fh)
+
+    @classmethod
+    def load(cls, path, solver=None):
+        with open(path) as fh:
+            return cls.from_dict(json.load(fh), solver)
