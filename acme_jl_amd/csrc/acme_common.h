@@ -1,0 +1,95 @@
+// acme_common.h -- POD types shared by the host packing code and the device kernels.
+//
+// Data layout of one circuit model in HBM/LDS ("model image"): every matrix of the
+// reference's DiscreteModel (src/ACME.jl:118-148) stored column-major and back to back,
+// exactly as Julia holds them, so that lane r of a 16-lane group reads row r of a matrix
+// at consecutive addresses (bank-conflict free) for a fixed column.
+#pragma once
+
+#ifndef ACME_HD
+#if defined(__HIPCC__)
+#define ACME_HD __host__ __device__
+#else
+#define ACME_HD
+#endif
+#endif
+
+namespace acme {
+
+constexpr int GROUP = 16;         // lanes per circuit instance = one DPP row
+constexpr int GROUPS_PER_WAVE = 4;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int INST_PER_BLOCK = GROUPS_PER_WAVE * WAVES_PER_BLOCK;
+constexpr int CHUNK = 16;         // samples staged per coalesced u/y transfer
+constexpr int ROWC = 24;          // precomputed constants per residual row
+constexpr int ROWI = 4;           // ints per residual row: kind, erow, qoff, flags
+constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8;
+
+// residual-row kinds (element kind of the row's element; same numbering as the element
+// kinds of include/acme_hip.h, plus PAD for rows added by host-side shape padding)
+enum RowKind { RK_NONE = 0, RK_DIODE = 1, RK_BJT = 2, RK_POT = 3, RK_MOSFET = 4, RK_MACAK = 5,
+               RK_JA = 6, RK_PAD = 7 };
+// row flags
+enum RowFlags { RF_EARLY = 1, RF_KNEE = 2, RF_ILE = 4, RF_ILC = 8, RF_ETAEL = 16, RF_ETACL = 32 };
+
+enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1 };
+
+struct Dims {
+    int nn, nq, np, nx, nu, ny;
+};
+
+// offsets (in doubles) of each matrix inside a model image
+struct Layout {
+    int dq, eq, pexp, fq, q0, a, b, c, x0, dy, ey, fy, y0, total;
+};
+
+ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int ny) {
+    Layout L{};
+    int o = 0;
+    L.dq = o;   o += np * nx;
+    L.eq = o;   o += np * nu;
+    L.pexp = o; o += nq * np;
+    L.fq = o;   o += nq * nn;
+    L.q0 = o;   o += nq;
+    L.a = o;    o += nx * nx;
+    L.b = o;    o += nx * nu;
+    L.c = o;    o += nx * nn;
+    L.x0 = o;   o += nx;
+    L.dy = o;   o += ny * nx;
+    L.ey = o;   o += ny * nu;
+    L.fy = o;   o += ny * nn;
+    L.y0 = o;   o += ny;
+    // tail padding: lanes beyond a matrix's row count read (finite) neighbours, never
+    // past the end of the image
+    o += 2 * GROUP;
+    L.total = (o + 1) & ~1;
+    return L;
+}
+
+// per-instance report (int64 words), mirrors the reference's failure semantics
+// (src/ACME.jl:688-694)
+enum ReportWord { RW_NWARN = 0, RW_FIRST_NONCONV = 1, RW_FIRST_NONFINITE = 2, RW_ITERS_TOTAL = 3,
+                  RW_ITERS_MAX = 4, RW_WORDS = 5 };
+
+struct KArgs {
+    const double *image;     // model image(s)
+    long long image_stride;  // 0: one shared image; else doubles between per-instance images
+    const double *rowc;      // ROWC x 16 row constants (const index major)
+    const int *rowi;         // ROWI x 16 row ints
+    const double *u;         // [n_inst][T][nu_io]
+    double *y;               // [n_inst][T][ny_io]
+    double *state;           // [n_inst][nx + np + nn] : x | last_p | last_z
+    long long *report;       // [n_inst][RW_WORDS]
+    long long n_inst;
+    long long T;
+    long long sample_base;   // global index of the first sample of this launch
+    double tol;
+    int maxiter;
+    int solver;
+    int nu_io, ny_io;        // strides of u / y in HBM (<= template NU / NY)
+    int nterms;              // max non-zeros per Jq row (2..4)
+    int has_bjt;             // any BJT row -> second exp needed
+    int rare_kinds;          // any MOSFET/MACAK/JA row
+};
+
+}  // namespace acme

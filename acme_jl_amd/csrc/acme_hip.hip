@@ -1,0 +1,95 @@
+// acme_hip.hip -- C ABI (include/acme_hip.h) over the gfx950 kernels of acme_kernel.h.
+//
+// Host side is deliberately thin: pack the model once, keep per-instance state resident in
+// HBM, launch one kernel per run! call on the caller's stream.  No CPU fallback exists:
+// without a usable HIP device every compute entry point fails with ACME_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/acme_hip.h"
+#include "acme_wave_hip.h"
+#include "acme_kernel.h"
+#include "acme_pack.h"
+
+using namespace acme;
+
+// ------------------------------------------------------------------------------------------
+// kernels: one instantiation per shape of acme_shapes.h
+// ------------------------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_run_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S>(A, acme_lds);
+}
+
+struct KernelEntry {
+    Dims d;
+    const void *fn;
+    int lds_shared, lds_per_inst;  // doubles
+    int state;                     // doubles of state per instance
+    int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
+};
+
+template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL(acme_run_kernel<S>, dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+    return (int)hipGetLastError();
+}
+
+static const std::vector<KernelEntry> &kernel_table() {
+    static const std::vector<KernelEntry> t = {
+#define ACME_X(nn, nq, np, nx, nu, ny)                                                              \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny>>, \
+                Shape<nn, nq, np, nx, nu, ny>::lds_doubles(false),                                   \
+                Shape<nn, nq, np, nx, nu, ny>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny>::STATE,  \
+                &launch_shape<Shape<nn, nq, np, nx, nu, ny>>},
+        ACME_SHAPES(ACME_X)
+#undef ACME_X
+    };
+    return t;
+}
+
+static const KernelEntry *find_kernel(const Dims &d) {
+    for (const auto &k : kernel_table())
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny)
+            return &k;
+    return nullptr;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// HIP device backend for acme_api.inc
+// ------------------------------------------------------------------------------------------
+namespace be {
+using stream_t = hipStream_t;
+using event_t = hipEvent_t;
+static inline const char *err_string(int e) { return hipGetErrorString((hipError_t)e); }
+static inline int device_count(int *n) { return (int)hipGetDeviceCount(n); }
+static inline int set_device(int d) { return (int)hipSetDevice(d); }
+static inline int get_device(int *d) { return (int)hipGetDevice(d); }
+static inline int set_max_lds(const void *fn, int bytes) {
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+static inline int dmalloc(void **p, size_t n) { return (int)hipMalloc(p, n ? n : 8); }
+static inline int dfree(void *p) { return p ? (int)hipFree(p) : 0; }
+static inline int copy_h2d(void *d, const void *s, size_t n) { return (int)hipMemcpy(d, s, n, hipMemcpyHostToDevice); }
+static inline int copy_d2h(void *d, const void *s, size_t n) { return (int)hipMemcpy(d, s, n, hipMemcpyDeviceToHost); }
+static inline int copy_h2d_async(void *d, const void *s, size_t n, stream_t st) {
+    return (int)hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st);
+}
+static inline int copy_d2h_async(void *d, const void *s, size_t n, stream_t st) {
+    return (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st);
+}
+static inline int device_sync() { return (int)hipDeviceSynchronize(); }
+static inline int stream_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
+static inline int event_create(event_t *e) { return (int)hipEventCreate(e); }
+static inline int event_destroy(event_t e) { return (int)hipEventDestroy(e); }
+static inline int event_record(event_t e, stream_t st) { return (int)hipEventRecord(e, st); }
+static inline int event_sync(event_t e) { return (int)hipEventSynchronize(e); }
+static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)hipEventElapsedTime(ms, a, b); }
+}  // namespace be
+
+#include "acme_api.inc"

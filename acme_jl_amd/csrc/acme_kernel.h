@@ -1,0 +1,724 @@
+// acme_kernel.h -- batched run!(::DiscreteModel, u) for gfx950: device code.
+//
+// Mapping (MI355X-first):
+//   * one circuit instance = one DPP row = 16 lanes; lane r owns ROW r of every small
+//     matrix (Jacobian / LU factors / Jp), element i of every short vector (x, p, z, res).
+//     A wavefront carries 4 instances, a 256-thread block 16.
+//   * row-local broadcasts (pivot row, x_j, z_j, p_j) are `row_newbcast` DPP moves, the
+//     pivot search is a 4-step `row_ror` max-reduction + one wave ballot; only the row
+//     interchange of the partially pivoted LU uses ds_bpermute.
+//   * the shared model matrices sit in LDS (column-major, so lane r reads row r of a
+//     column at consecutive addresses); per-instance state stays in registers for the
+//     whole launch and touches HBM once at either end; u / y stream through LDS in
+//     coalesced CHUNK-sample tiles.
+//   * Newton iteration counts are data dependent: every loop is driven by a wave ballot
+//     over per-instance "still active" masks; finished instances idle as masked lanes.
+//
+// Reference semantics restated here (file:line in the ACME.jl tree):
+//   step!            src/ACME.jl:666-715      evaluate!/closures  src/ACME.jl:176-194,236-252
+//   SimpleSolver     src/solvers.jl:151-236   HomotopySolver      src/solvers.jl:247-302
+//   LinearSolver     src/solvers.jl:38-132    element functions   src/elements.jl (per kind)
+//
+// The including translation unit must provide namespace wv (cross-lane primitives) and
+// ACME_DEV before including this header (acme_wave_hip.h on the GPU).
+#pragma once
+#include <math.h>
+
+#include <type_traits>
+
+#include "acme_common.h"
+
+#ifndef ACME_LAMBDA
+#define ACME_LAMBDA __attribute__((always_inline))
+#endif
+#ifndef ACME_DBG  // debug trace hook, only ever defined by the CPU wave emulator
+#define ACME_DBG(...)
+#endif
+
+namespace acme {
+
+template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_> struct Shape {
+    static constexpr int NN = NN_, NQ = NQ_, NP = NP_, NX = NX_, NU = NU_, NY = NY_;
+    static constexpr int NQS = (NQ + GROUP - 1) / GROUP;  // q rows per lane
+    static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
+    static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
+    static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY);
+    // per-instance LDS scratch (doubles): q exchange | u tile | y tile
+    static constexpr int QBUF = GROUP * (NQS > 0 ? NQS : 1) + 8;
+    static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY;
+    static constexpr int SCRATCH = (QBUF + UBUF + YBUF + 1) & ~1;
+    static constexpr int STATE = NX + NP + NN;  // doubles of persistent state per instance
+    ACME_HD static constexpr int lds_doubles(bool per_instance) {
+        return (per_instance ? INST_PER_BLOCK : 1) * L.total + ROWC * GROUP + ROWI * GROUP +
+               INST_PER_BLOCK * SCRATCH;
+    }
+};
+
+// compile-time counted loops (indices are template constants: DPP lane selects and
+// register-array subscripts must be immediates)
+template <int I, int N, class F> ACME_DEV void sfor(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+template <int I, class F> ACME_DEV void sfor_down(F &&f) {  // I-1 ... 0
+    if constexpr (I > 0) {
+        f(std::integral_constant<int, I - 1>{});
+        sfor_down<I - 1>(f);
+    }
+}
+
+ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
+ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
+
+// ---------------------------------------------------------------------------------------
+// LinearSolver, row-per-lane (src/solvers.jl:46-132).  a[j] = element (lig, j).
+// ---------------------------------------------------------------------------------------
+template <int NN> struct RowLU {
+    // setlhs!: in-place LU with partial pivoting (first strict max), reciprocal pivots on
+    // the diagonal.  `orig` returns the original row now stored in this lane (the composed
+    // row interchanges).  Returns false for an exactly singular matrix.
+    static ACME_DEV bool factor(double (&a)[NN > 0 ? NN : 1], int &orig, int lig, int grp) {
+        bool ok = true;
+        orig = lig;
+        sfor<0, NN>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = decltype(kc)::value;
+            double v = (lig >= k && lig < NN) ? fabs(a[k]) : -1.0;
+            double m = wv::allmax16(v);
+            unsigned long long bal = wv::ballot(v == m);
+            int msk = (int)((bal >> (grp * GROUP)) & 0xFFFFull);
+            int kp = wv::ffs32(msk) - 1;          // first row holding the maximum
+            ok = ok && (m > 0.0);
+            if (wv::ballot(kp != k)) {            // some instance of this wave interchanges
+                int src = (lig == k) ? kp : ((lig == kp) ? k : lig);
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    a[j] = wv::shfl16(a[j], src);
+                });
+                orig = wv::shfl16(orig, src);
+            }
+            double piv = wv::bcast16<k>(a[k]);
+            double inv = 1.0 / piv;
+            double l = a[k] * inv;
+            a[k] = (lig == k) ? inv : ((lig > k) ? l : a[k]);
+            double lm = (lig > k) ? l : 0.0;
+            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                a[j] = fma(-lm, wv::bcast16<k>(a[j]), a[j]);
+            });
+        });
+        return ok;
+    }
+
+    // solve!: b is distributed one element per lane; returns x likewise
+    static ACME_DEV double solve(const double (&a)[NN > 0 ? NN : 1], int orig, double b, int lig) {
+        double t = wv::shfl16(b, orig);           // all row interchanges at once
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA {                // unit lower triangle
+            constexpr int j = decltype(jc)::value;
+            double xj = wv::bcast16<j>(t);
+            double lm = (lig > j) ? a[j] : 0.0;
+            t = fma(-lm, xj, t);
+        });
+        sfor_down<NN>([&](auto jc) ACME_LAMBDA {              // upper triangle, reciprocal diagonal
+            constexpr int j = decltype(jc)::value;
+            t = (lig == j) ? a[j] * t : t;
+            double xj = wv::bcast16<j>(t);
+            double um = (lig < j) ? a[j] : 0.0;
+            t = fma(-um, xj, t);
+        });
+        return t;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// element nonlinearities, one residual row per lane (src/elements.jl)
+// ---------------------------------------------------------------------------------------
+struct RowDesc {
+    int kind, erow, qoff, flags;
+    const double *rc;  // row constants in LDS: rc[c * GROUP]
+};
+
+ACME_DEV double rcv(const RowDesc &rd, int c) { return rd.rc[c * GROUP]; }
+
+// res and up to four Jq non-zeros (value tv[t] in q column tc[t]) of this lane's row.
+// e[0..4] are the element's q entries, exA/exB the hoisted exponentials.
+ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, double exB,
+                       bool rare, double &res, double (&tv)[4], int (&tc)[4]) {
+    res = 0.0;
+    tv[0] = tv[1] = tv[2] = tv[3] = 0.0;
+    tc[0] = tc[1] = tc[2] = tc[3] = rd.qoff;
+    const int kind = rd.kind;
+    if (kind == RK_DIODE) {  // src/elements.jl:238-244
+        res = rcv(rd, 1) * (exA - 1.0) - e[1];
+        tv[0] = rcv(rd, 2) * exA;
+        tv[1] = -1.0;
+        tc[1] = rd.qoff + 1;
+    } else if (kind == RK_BJT) {  // src/elements.jl:323-401
+        const int fl = rd.flags;
+        double vE = e[0], vC = e[1];
+        double expE = exA, expC = exB;
+        double i_f = rcv(rd, 2) * (expE - 1.0);
+        double i_r = rcv(rd, 3) * (expC - 1.0);
+        double di_f1 = rcv(rd, 4) * expE;
+        double di_r2 = rcv(rd, 5) * expC;
+        double i_cc = i_f - i_r, di_cc1 = di_f1, di_cc2 = -di_r2;
+        if (fl & (RF_EARLY | RF_KNEE)) {
+            if (!(fl & RF_KNEE)) {  // Early effect only (:335-343)
+                double q1i = 1.0 - vE * rcv(rd, 8) - vC * rcv(rd, 9);
+                i_cc = q1i * (i_f - i_r);
+                di_cc1 = rcv(rd, 18) * (i_f - i_r) + q1i * di_f1;
+                di_cc2 = rcv(rd, 19) * (i_f - i_r) - q1i * di_r2;
+            } else if (!(fl & RF_EARLY)) {  // high-level injection only (:344-356)
+                double q2 = i_f * rcv(rd, 10) + i_r * rcv(rd, 11);
+                double qden = 1.0 + sqrt(1.0 + 4.0 * q2);
+                double qfact = 2.0 / qden;
+                i_cc = qfact * (i_f - i_r);
+                double dq21 = di_f1 * rcv(rd, 10), dq22 = di_r2 * rcv(rd, 11);
+                double dqfact1 = -4.0 * dq21 / (qden - 1.0) / (qden * qden);
+                double dqfact2 = -4.0 * dq22 / (qden - 1.0) / (qden * qden);
+                di_cc1 = dqfact1 * (i_f - i_r) + qfact * di_f1;
+                di_cc2 = dqfact2 * (i_f - i_r) - qfact * di_r2;
+            } else {  // both (:357-373)
+                double q1i = 1.0 - vE * rcv(rd, 8) - vC * rcv(rd, 9);
+                double q2 = i_f * rcv(rd, 10) + i_r * rcv(rd, 11);
+                double qden = 1.0 + sqrt(1.0 + 4.0 * q2);
+                double qfact = 2.0 * q1i / qden;
+                i_cc = qfact * (i_f - i_r);
+                double dq21 = di_f1 * rcv(rd, 10), dq22 = di_r2 * rcv(rd, 11);
+                double dqfact1 = (2.0 * rcv(rd, 18) * qden - q1i * 4.0 * dq21 / (qden - 1.0)) / (qden * qden);
+                double dqfact2 = (2.0 * rcv(rd, 19) * qden - q1i * 4.0 * dq22 / (qden - 1.0)) / (qden * qden);
+                di_cc1 = dqfact1 * (i_f - i_r) + qfact * di_f1;
+                di_cc2 = dqfact2 * (i_f - i_r) - qfact * di_r2;
+            }
+        }
+        double iBE = rcv(rd, 6) * i_f, diBE1 = rcv(rd, 6) * di_f1;
+        double iBC = rcv(rd, 7) * i_r, diBC2 = rcv(rd, 7) * di_r2;
+        if (fl & RF_ILE) {  // :377-385
+            double expEl = (fl & RF_ETAEL) ? exp(vE * rcv(rd, 14)) : expE;
+            iBE += rcv(rd, 12) * (expEl - 1.0);
+            diBE1 += rcv(rd, 16) * expEl;
+        }
+        if (fl & RF_ILC) {  // :388-396
+            double expCl = (fl & RF_ETACL) ? exp(vC * rcv(rd, 15)) : expC;
+            iBC += rcv(rd, 13) * (expCl - 1.0);
+            diBC2 += rcv(rd, 17) * expCl;
+        }
+        tc[1] = rd.qoff + 1;
+        tv[2] = -1.0;
+        if (rd.erow == 0) {
+            res = i_cc + iBE - e[2];
+            tv[0] = di_cc1 + diBE1;
+            tv[1] = di_cc2;
+            tc[2] = rd.qoff + 2;
+        } else {
+            res = -i_cc + iBC - e[3];
+            tv[0] = -di_cc1;
+            tv[1] = -di_cc2 + diBC2;
+            tc[2] = rd.qoff + 3;
+        }
+    } else if (kind == RK_POT) {  // src/elements.jl:25-30
+        double r = rcv(rd, 0);
+        tv[0] = 1.0;
+        tc[2] = rd.qoff + 4;
+        if (rd.erow == 0) {
+            res = e[0] - r * e[4] * e[2];
+            tv[1] = -r * e[4];
+            tv[2] = -r * e[2];
+            tc[1] = rd.qoff + 2;
+        } else {
+            res = e[1] - r * (1.0 - e[4]) * e[3];
+            tv[1] = -r * (1.0 - e[4]);
+            tv[2] = -r * e[3];
+            tc[0] = rd.qoff + 1;
+            tc[1] = rd.qoff + 3;
+        }
+    } else if (kind == RK_PAD) {  // host-side shape padding: res = q, keeps z_pad = 0
+        res = e[0];
+        tv[0] = 1.0;
+    } else if (rare) {
+        if (kind == RK_MOSFET) {  // src/elements.jl:453-479
+            double pol = rcv(rd, 0), lam = rcv(rd, 1);
+            int nvt = (int)rcv(rd, 2), na = (int)rcv(rd, 7);
+            double vgs = e[0], vds = e[1], id = e[2];
+            double xg = pol * vgs;
+            // Horner (Base.evalpoly); derivative coefficients k*c_k at rc[12..14], rc[15..17]
+            double a_ = rcv(rd, 8 + na - 1), da = (na > 1) ? rcv(rd, 15 + na - 2) : 0.0;
+            for (int k = na - 2; k >= 0; --k) a_ = a_ * xg + rcv(rd, 8 + k);
+            for (int k = na - 3; k >= 0; --k) da = da * xg + rcv(rd, 15 + k);
+            double vt_ = rcv(rd, 3 + nvt - 1), dvt_ = (nvt > 1) ? rcv(rd, 12 + nvt - 2) : 0.0;
+            for (int k = nvt - 2; k >= 0; --k) vt_ = vt_ * xg + rcv(rd, 3 + k);
+            for (int k = nvt - 3; k >= 0; --k) dvt_ = dvt_ * xg + rcv(rd, 12 + k);
+            double lam_ = vds >= 0.0 ? lam : 0.0;
+            tc[1] = rd.qoff + 1;
+            tc[2] = rd.qoff + 2;
+            tv[2] = -1.0;
+            if (vgs <= vt_) {
+                res = -id;
+            } else if (vds <= vgs - vt_) {
+                res = a_ * (vgs - vt_ - 0.5 * vds) * vds * (1.0 + lam_ * vds) - id;
+                tv[0] = a_ * (1.0 - dvt_) * vds * (1.0 + lam_ * vds) +
+                        da * (vgs - vt_ - 0.5 * vds) * vds * (1.0 + lam_ * vds);
+                tv[1] = a_ * (vgs - vt_ + vds * (2.0 * lam_ * (vgs - vt_ - 0.75 * vds) - 1.0));
+            } else {
+                double d = vgs - vt_;
+                res = (a_ / 2.0) * (d * d) * (1.0 + lam_ * vds) - id;
+                tv[0] = a_ * d * (1.0 - dvt_) * (1.0 + lam_ * vds) + da / 2.0 * (d * d) * (1.0 + lam_ * vds);
+                tv[1] = lam_ * a_ / 2.0 * (d * d);
+            }
+        } else if (kind == RK_MACAK) {  // src/elements.jl:540-546
+            double gain = rcv(rd, 0), scale = rcv(rd, 1);
+            double vs = e[0] * rcv(rd, 2);  // gain / scale
+            double ch = cosh(vs);
+            res = tanh(vs) * scale - e[1];
+            tv[0] = gain / (ch * ch);
+            tv[1] = -1.0;
+            tc[1] = rd.qoff + 1;
+        } else if (kind == RK_JA) {  // src/elements.jl:107-129
+            double Ms = rcv(rd, 0), al = rcv(rd, 2), c = rcv(rd, 3), k = rcv(rd, 4);
+            double s = rcv(rd, 5);    // 1e-4 / Ms
+            double cMa = rcv(rd, 6);  // c * Ms / a
+            double q1 = e[0], q2 = e[1], q3 = e[2], q4 = e[3];
+            double coth = 1.0 / tanh(q1);
+            double aq1 = fabs(q1);
+            double Lq = aq1 < 1e-4 ? q1 / 3.0 : coth - 1.0 / q1;
+            double Ld = aq1 < 1e-4 ? 1.0 / 3.0 : 1.0 / (q1 * q1) - coth * coth + 1.0;
+            double Ld2 = aq1 < 1e-3 ? -2.0 / 15.0 * q1 : 2.0 * coth * (coth * coth - 1.0) - 2.0 / (q1 * q1 * q1);
+            double delta = q3 > 0.0 ? 1.0 : -1.0;
+            double Man = Ms * Lq;
+            double d = Man - q2;
+            int s3 = (q3 > 0.0) - (q3 < 0.0), sd = (d > 0.0) - (d < 0.0);
+            double dM = (s3 == sd) ? 1.0 : 0.0;
+            double den = delta * (k * (1.0 - c)) - al * d;
+            res = s * ((1.0 - c) * dM * d / den * q3 + cMa * (q3 + al * q4) * Ld - q4);
+            tv[0] = s * (((1.0 - c) * (1.0 - c) * k * Ms) * dM * Ld * delta / (den * den) * q3 +
+                         cMa * (q3 + al * q4) * Ld2);
+            tv[1] = s * -((1.0 - c) * (1.0 - c)) * k * dM * delta / (den * den) * q3;
+            tv[2] = s * ((1.0 - c) * dM * d / den + cMa * Ld);
+            tv[3] = s * (rcv(rd, 7) * Ld - 1.0);  // c*Ms/a*alpha
+            tc[1] = rd.qoff + 1;
+            tc[2] = rd.qoff + 2;
+            tc[3] = rd.qoff + 3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// the per-wave time loop
+// ---------------------------------------------------------------------------------------
+template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
+    constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
+    constexpr int NQS = S::NQS, NXS = S::NXS;
+    constexpr int NNr = NN > 0 ? NN : 1, NPr = NP > 0 ? NP : 1, NQSr = NQS > 0 ? NQS : 1,
+                  NXSr = NXS > 0 ? NXS : 1;
+    constexpr Layout L = S::L;
+    using LU = RowLU<NN>;
+
+    const int tid = wv::tid();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lig = lane & (GROUP - 1), grp = lane >> 4;
+    const int gib = wave * GROUPS_PER_WAVE + grp;  // group in block
+    const long long inst = (long long)wv::bid() * INST_PER_BLOCK + gib;
+    const bool per_inst = A.image_stride != 0;
+    const bool valid = inst < A.n_inst;
+
+    // ---- LDS carve-up -------------------------------------------------------------------
+    double *lds_img = lds;
+    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;
+    int *lds_rowi = (int *)(lds_rowc + ROWC * GROUP);
+    double *lds_scr = lds_rowc + ROWC * GROUP + ROWI * GROUP;
+    {   // cooperative load of the model image(s) and the row tables
+        const int nthreads = WAVES_PER_BLOCK * 64;
+        if (!per_inst) {
+            for (int i = tid; i < L.total; i += nthreads) lds_img[i] = A.image[i];
+        } else {
+            for (int g = 0; g < INST_PER_BLOCK; ++g) {
+                long long ii = (long long)wv::bid() * INST_PER_BLOCK + g;
+                if (ii >= A.n_inst) ii = A.n_inst - 1;
+                const double *src = A.image + ii * A.image_stride;
+                for (int i = tid; i < L.total; i += nthreads) lds_img[g * L.total + i] = src[i];
+            }
+        }
+        for (int i = tid; i < ROWC * GROUP; i += nthreads) lds_rowc[i] = A.rowc[i];
+        for (int i = tid; i < ROWI * GROUP; i += nthreads) lds_rowi[i] = A.rowi[i];
+    }
+    wv::block_sync();
+
+    const double *M = lds_img + (per_inst ? gib * L.total : 0);
+    double *qbuf = lds_scr + gib * S::SCRATCH;
+    double *ubuf = qbuf + S::QBUF;
+    double *ybuf = ubuf + S::UBUF;
+
+    // zero this instance's scratch once: with a padded shape (nu_io < NU, nq < NQ) some
+    // u-tile / q-exchange entries are read but never written
+    for (int i = lig; i < S::SCRATCH; i += GROUP) qbuf[i] = 0.0;
+    wv::wave_fence();
+
+    RowDesc rd;
+    rd.kind = (lig < NN) ? lds_rowi[0 * GROUP + lig] : RK_NONE;
+    rd.erow = lds_rowi[1 * GROUP + lig];
+    rd.qoff = lds_rowi[2 * GROUP + lig];
+    rd.flags = lds_rowi[3 * GROUP + lig];
+    rd.rc = lds_rowc + lig;
+    const bool rare = A.rare_kinds != 0;
+    const bool has_bjt = A.has_bjt != 0;
+    const int nterms = A.nterms;
+
+    // ---- persistent per-instance state, in registers for the whole launch --------------
+    double x[NXSr];      // state vector, element s*16+lig
+    double lp = 0.0;     // extrapolation origin: last_p[lig]
+    double lz = 0.0;     //                       last_z[lig]
+    double lu[NNr];      // last_linsolver factors, row lig
+    int lorig = lig;     //   and its row permutation
+    double ljp[NPr];     // last_Jp, row lig
+    double z = 0.0;      // current iterate z[lig]
+    double pfull[NQSr];  // q0 + pexp*p, rows s*16+lig
+    // per-row results of the latest evaluate!
+    double a[NNr];       // J row -> LU row
+    int orig = lig;
+    double res = 0.0;
+    double tv[4];
+    int tc[4];
+
+    double *st = A.state + (valid ? inst : 0) * S::STATE;
+    sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+        constexpr int s = decltype(sc)::value;
+        int i = s * GROUP + lig;
+        x[s] = (valid && i < NX) ? st[i] : 0.0;
+    });
+    if (NP > 0) lp = (valid && lig < NP) ? st[NX + lig] : 0.0;
+    if (NN > 0) lz = (valid && lig < NN) ? st[NX + NP + lig] : 0.0;
+
+    // ---- helpers ------------------------------------------------------------------------
+    // pfull <- q0 + pexp*p   (set_p closure, src/ACME.jl:237-243)
+    auto set_p = [&](double p) ACME_LAMBDA {
+        sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
+            constexpr int s = decltype(sc)::value;
+            pfull[s] = M[L.q0 + s * GROUP + lig];
+        });
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+            constexpr int j = decltype(jc)::value;
+            double pj = wv::bcast16<j>(p);
+            sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
+                constexpr int s = decltype(sc)::value;
+                pfull[s] = fma(M[L.pexp + j * NQ + s * GROUP + lig], pj, pfull[s]);
+            });
+        });
+    };
+
+    // evaluate!(nleq, z): q = pfull + fq*z; (res, Jq) = elements(q); J = Jq*fq
+    // (src/ACME.jl:178-188, src/circuit.jl:10-17).  Leaves J row in a[], residual in res,
+    // the row's Jq non-zeros in tv/tc.  Returns true if res and J are finite.
+    auto evaluate = [&](double zz) ACME_LAMBDA -> bool {
+        double q[NQSr];
+        sfor<0, NQS>([&](auto sc) ACME_LAMBDA { q[decltype(sc)::value] = pfull[decltype(sc)::value]; });
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+            constexpr int j = decltype(jc)::value;
+            double zj = wv::bcast16<j>(zz);
+            sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
+                constexpr int s = decltype(sc)::value;
+                q[s] = fma(M[L.fq + j * NQ + s * GROUP + lig], zj, q[s]);
+            });
+        });
+        wv::wave_fence();
+        sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
+            constexpr int s = decltype(sc)::value;
+            qbuf[s * GROUP + lig] = q[s];
+        });
+        wv::wave_fence();
+        double e[5];
+        e[0] = qbuf[rd.qoff];
+        e[1] = qbuf[rd.qoff + 1];
+        e[2] = qbuf[rd.qoff + 2];
+        e[3] = qbuf[rd.qoff + 3];
+        e[4] = qbuf[rd.qoff + 4];
+        // hoisted exponentials: diode exp(v/(eta vT)), BJT exp(vE/..), exp(vC/..)
+        double argA = 0.0, argB = 0.0;
+        if (rd.kind == RK_DIODE || rd.kind == RK_BJT) argA = e[0] * rcv(rd, 0);
+        if (rd.kind == RK_BJT) argB = e[1] * rcv(rd, 1);
+        double exA = exp(argA);
+        double exB = has_bjt ? exp(argB) : 1.0;
+        eval_row(rd, e, exA, exB, rare, res, tv, tc);
+        double chk = res * 0.0;
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+            constexpr int j = decltype(jc)::value;
+            double acc = tv[0] * M[L.fq + j * NQ + tc[0]];
+            acc = fma(tv[1], M[L.fq + j * NQ + tc[1]], acc);
+            if (nterms > 2) acc = fma(tv[2], M[L.fq + j * NQ + tc[2]], acc);
+            if (nterms > 3) acc = fma(tv[3], M[L.fq + j * NQ + tc[3]], acc);
+            a[j] = acc;
+            chk = fma(acc, 0.0, chk);
+        });
+        // non-finite anywhere in this instance's res / J ?
+        unsigned long long bad = wv::ballot(lig < NN && !(chk == 0.0));
+        return ((bad >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+    };
+
+    // calc_Jp closure (src/ACME.jl:246-251): Jp row = Jq row * pexp
+    auto calc_jp = [&](double (&jp)[NPr]) {
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+            constexpr int j = decltype(jc)::value;
+            double acc = tv[0] * M[L.pexp + j * NQ + tc[0]];
+            acc = fma(tv[1], M[L.pexp + j * NQ + tc[1]], acc);
+            if (nterms > 2) acc = fma(tv[2], M[L.pexp + j * NQ + tc[2]], acc);
+            if (nterms > 3) acc = fma(tv[3], M[L.pexp + j * NQ + tc[3]], acc);
+            jp[j] = acc;
+        });
+    };
+
+    // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196): the factors and Jp
+    // at the origin are recomputed from (p, z), so only (p, z) has to persist in HBM.
+    if (NN > 0) {
+        set_p(lp);
+        evaluate(lz);
+        LU::factor(a, orig, lig, grp);
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA { lu[decltype(jc)::value] = a[decltype(jc)::value]; });
+        lorig = orig;
+        calc_jp(ljp);
+        z = lz;
+        ACME_DBG("origin lane %d kind %d qoff %d res %.17g tv %g %g tc %d %d lu %.17g %.17g lorig %d ljp %.17g pfull %g", lane, rd.kind, rd.qoff, res, tv[0], tv[1], tc[0], tc[1], lu[0], lu[NN > 1 ? 1 : 0], lorig, ljp[0], pfull[0]);
+    }
+
+    // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
+    // returns hasconverged, leaves needediterations in `its`.
+    auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
+        set_p(target);
+        // z <- last_z - last_J \ (last_Jp * (p - last_p))
+        double dp = target - lp;
+        double t = 0.0;
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+            constexpr int j = decltype(jc)::value;
+            t = fma(ljp[j], wv::bcast16<j>(dp), t);
+        });
+        t = LU::solve(lu, lorig, t, lig);
+        z = sel(need, lz - t, z);
+        bool act = need, conv = false;
+        its = 0;
+        while (wv::ballot(act)) {
+            its = act ? its + 1 : its;
+            bool finite = evaluate(z);
+            double rm = wv::allmax16((lig < NN) ? fabs(res) : 0.0);
+            ACME_DBG("  it %d lane %d act %d z %.17g res %.17g J0 %.17g finite %d rm %g", its, lane, (int)act, z, res, a[0], (int)finite, rm);
+            bool ok = LU::factor(a, orig, lig, grp);  // LU before the convergence test
+            bool small = rm < A.tol;
+            bool stop_bad = act && (!finite || !ok);
+            bool stop_conv = act && finite && ok && small;
+            // hasconverged is evaluated on resmaxabs even after a singular-J return
+            conv = stop_bad ? (finite && small) : (stop_conv ? true : conv);
+            if (wv::ballot(stop_conv)) {  // refresh the extrapolation origin (:231-234)
+                double jp[NPr];
+                calc_jp(jp);
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    lu[j] = sel(stop_conv, a[j], lu[j]);
+                });
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    ljp[j] = sel(stop_conv, jp[j], ljp[j]);
+                });
+                lorig = sel(stop_conv, orig, lorig);
+                lz = sel(stop_conv, z, lz);
+                lp = sel(stop_conv, target, lp);
+            }
+            bool step = act && !stop_bad && !stop_conv;
+            double dz = LU::solve(a, orig, res, lig);
+            z = sel(step, z - dz, z);
+            act = step && (its < A.maxiter);
+        }
+        return conv;
+    };
+
+    // ---- report words -------------------------------------------------------------------
+    long long n_warn = 0, first_nonconv = -1, first_nonfinite = -1, iters_total = 0;
+    int iters_max = 0;
+    bool dead = !valid;  // dead: the reference would have thrown at first_nonfinite
+    if (valid) {
+        const long long *rp = A.report + inst * RW_WORDS;
+        n_warn = rp[RW_NWARN];
+        first_nonconv = rp[RW_FIRST_NONCONV];
+        first_nonfinite = rp[RW_FIRST_NONFINITE];
+        iters_total = rp[RW_ITERS_TOTAL];
+        iters_max = (int)rp[RW_ITERS_MAX];
+        dead = first_nonfinite >= 0;
+    }
+
+    // ---- time loop ----------------------------------------------------------------------
+    const long long T = A.T;
+    const int nu_io = A.nu_io, ny_io = A.ny_io;
+    const double *ug = A.u + (valid ? inst : 0) * T * nu_io;
+    double *yg = A.y + (valid ? inst : 0) * T * ny_io;
+    double upre[S::NUR];
+    auto prefetch_u = [&](long long n0) ACME_LAMBDA {
+        long long cnt = T - n0;
+        if (cnt > CHUNK) cnt = CHUNK;
+        sfor<0, NU>([&](auto ic) ACME_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            long long e = lig + GROUP * i;
+            upre[i] = (valid && e < cnt * nu_io) ? ug[n0 * nu_io + e] : 0.0;
+        });
+    };
+    if (NU > 0) prefetch_u(0);
+
+    for (long long n0 = 0; n0 < T; n0 += CHUNK) {
+        int cnt = (int)((T - n0 < CHUNK) ? (T - n0) : CHUNK);
+        if (NU > 0) {
+            wv::wave_fence();
+            sfor<0, NU>([&](auto ic) ACME_LAMBDA {
+                constexpr int i = decltype(ic)::value;
+                int e = lig + GROUP * i;
+                if (e < CHUNK * nu_io) ubuf[(e / nu_io) * NU + (e % nu_io)] = upre[i];
+            });
+            wv::wave_fence();
+            if (n0 + CHUNK < T) prefetch_u(n0 + CHUNK);
+        }
+        for (int m = 0; m < cnt; ++m) {
+            const long long n = A.sample_base + n0 + m;
+            const bool alive = !dead;
+            double zfin = 0.0;
+            if (NN > 0) {
+                // p = dq*x + eq*u  (src/ACME.jl:678-683)
+                double p = 0.0;
+                sfor<0, NX>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
+                    p = fma(M[L.dq + j * NP + lig], xj, p);
+                });
+                sfor<0, NU>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = decltype(kc)::value;
+                    p = fma(M[L.eq + k * NP + lig], ubuf[m * NU + k], p);
+                });
+                // solve(::HomotopySolver, p) (src/solvers.jl:268-296) as a per-instance
+                // state machine; every base solve is shared by the wave
+                bool need = alive, conv = false;
+                int mode = 0, its_sample = 0;
+                double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
+                ACME_DBG("sample %lld lane %d p %.17g x %.17g lp %.17g lz %.17g", n, lane, p, x[0], lp, lz);
+                while (wv::ballot(need)) {
+                    int its;
+                    bool c = base_solve(target, need, its);
+                    its_sample += need ? its : 0;
+                    conv = need ? c : conv;
+                    if (A.solver == SOLVER_SIMPLE) {
+                        need = false;
+                    } else {
+                        bool direct = need && mode == 0;
+                        bool homot = need && mode == 1;
+                        // direct attempt failed -> start bisection from the origin's p
+                        bool start = direct && !c;
+                        startp = sel(start, lp, startp);
+                        // homotopy step bookkeeping
+                        bool hgood = homot && c;
+                        hbest = sel(hgood, ha, hbest);
+                        double new_a = (ha + hbest) / 2.0;
+                        bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
+                        ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
+                        ha = sel(start, 0.5, ha);
+                        hbest = sel(start, 0.0, hbest);
+                        mode = sel(start, 1, mode);
+                        need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
+                        double pa = startp * (1.0 - ha);
+                        pa = pa + ha * p;
+                        target = sel(need, pa, target);
+                    }
+                }
+                zfin = z;
+                // convergence policy of step! (src/ACME.jl:688-694)
+                unsigned long long nf = wv::ballot(lig < NN && !(z * 0.0 == 0.0));
+                bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+                bool failed = alive && !conv;
+                if (wv::ballot(failed)) {
+                    bool warn = failed && zfinite;
+                    bool die = failed && !zfinite;
+                    n_warn += warn ? 1 : 0;
+                    first_nonconv = (warn && first_nonconv < 0) ? n : first_nonconv;
+                    first_nonfinite = (die && first_nonfinite < 0) ? n : first_nonfinite;
+                    dead = dead || die;
+                }
+                iters_total += alive ? its_sample : 0;
+                iters_max = (alive && its_sample > iters_max) ? its_sample : iters_max;
+            }
+            const bool live = !dead;
+            // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
+            if (NY > 0) {
+                double yy = M[L.y0 + lig];
+                sfor<0, NX>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    yy = fma(M[L.dy + j * NY + lig], wv::bcast16<j % GROUP>(x[j / GROUP]), yy);
+                });
+                sfor<0, NU>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = decltype(kc)::value;
+                    yy = fma(M[L.ey + k * NY + lig], ubuf[m * NU + k], yy);
+                });
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    yy = fma(M[L.fy + j * NY + lig], wv::bcast16<j>(zfin), yy);
+                });
+                if (lig < NY) ybuf[m * NY + lig] = live ? yy : (double)NAN;
+            }
+            // x = x0 + a*x + b*u + c*z  (src/ACME.jl:708-714)
+            if (NX > 0) {
+                double xn[NXSr];
+                sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                    constexpr int s = decltype(sc)::value;
+                    xn[s] = M[L.x0 + s * GROUP + lig];
+                });
+                sfor<0, NX>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
+                    sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                        constexpr int s = decltype(sc)::value;
+                        xn[s] = fma(M[L.a + j * NX + s * GROUP + lig], xj, xn[s]);
+                    });
+                });
+                sfor<0, NU>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = decltype(kc)::value;
+                    double uk = ubuf[m * NU + k];
+                    sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                        constexpr int s = decltype(sc)::value;
+                        xn[s] = fma(M[L.b + k * NX + s * GROUP + lig], uk, xn[s]);
+                    });
+                });
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    double zj = wv::bcast16<j>(zfin);
+                    sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                        constexpr int s = decltype(sc)::value;
+                        xn[s] = fma(M[L.c + j * NX + s * GROUP + lig], zj, xn[s]);
+                    });
+                });
+                sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                    constexpr int s = decltype(sc)::value;
+                    x[s] = sel(live, xn[s], x[s]);
+                });
+            }
+        }
+        // flush the y tile, coalesced
+        if (NY > 0) {
+            wv::wave_fence();
+            for (int e = lig; e < cnt * ny_io; e += GROUP)
+                if (valid) yg[n0 * ny_io + e] = ybuf[(e / ny_io) * NY + (e % ny_io)];
+            wv::wave_fence();
+        }
+    }
+
+    // ---- write back state and report ----------------------------------------------------
+    if (valid) {
+        sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+            constexpr int s = decltype(sc)::value;
+            int i = s * GROUP + lig;
+            if (i < NX) st[i] = x[s];
+        });
+        if (NP > 0 && lig < NP) st[NX + lig] = lp;
+        if (NN > 0 && lig < NN) st[NX + NP + lig] = lz;
+        if (lig == 0) {
+            long long *rp = A.report + inst * RW_WORDS;
+            rp[RW_NWARN] = n_warn;
+            rp[RW_FIRST_NONCONV] = first_nonconv;
+            rp[RW_FIRST_NONFINITE] = first_nonfinite;
+            rp[RW_ITERS_TOTAL] = iters_total;
+            rp[RW_ITERS_MAX] = iters_max;
+        }
+    }
+}
+
+}  // namespace acme

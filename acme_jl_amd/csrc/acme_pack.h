@@ -1,0 +1,244 @@
+// acme_pack.h -- host-side packing of a DiscreteModel into the device "model image"
+// plus the per-row element tables (pure C++, no HIP; shared by the HIP library and the
+// wave emulator used in CPU tests).
+//
+// The reference passes the nonlinearity as Julia closures (ParametricNonLinEq,
+// src/solvers.jl:6-36; CircuitNLFunc, src/circuit.jl:6-20,68-86).  Closures cannot cross
+// a C ABI, so the model carries an element table instead; here it is flattened to one
+// descriptor per residual row (= per lane) with every loop-invariant sub-expression of
+// the element functions (src/elements.jl) pre-evaluated in the same operation order.
+#pragma once
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "acme_common.h"
+#include "acme_shapes.h"
+
+namespace acme {
+
+constexpr int MAX_ELEM_PAR = 16;
+enum ElemKind { EK_DIODE = 1, EK_BJT = 2, EK_POT = 3, EK_MOSFET = 4, EK_MACAK = 5, EK_JA = 6 };
+
+struct HostSub {
+    int nn = 0, nq = 0, np = 0;
+    std::vector<double> pexp, dq, eq, fqprev, fq, q0, init_z;
+    std::vector<int> kind, qoff, roff;
+    std::vector<double> par;  // n_elems x MAX_ELEM_PAR
+};
+
+struct HostModel {
+    int nx = 0, nu = 0, ny = 0, nn_total = 0;
+    std::vector<double> a, b, c, x0, dy, ey, fy, y0;
+    std::vector<HostSub> subs;
+};
+
+struct Packed {
+    Dims shape{};   // instantiated kernel shape
+    Dims actual{};  // the model's own dimensions
+    std::vector<double> image, rowc, init_state;
+    std::vector<int> rowi;
+    int nterms = 2, has_bjt = 0, rare_kinds = 0;
+};
+
+inline const std::vector<Dims> &shape_list() {
+    static const std::vector<Dims> v = {
+#define ACME_X(nn, nq, np, nx, nu, ny) Dims{nn, nq, np, nx, nu, ny},
+        ACME_SHAPES(ACME_X)
+#undef ACME_X
+    };
+    return v;
+}
+
+inline void kind_shape(int kind, int &nq, int &nn) {
+    switch (kind) {
+    case EK_DIODE: nq = 2; nn = 1; break;
+    case EK_BJT: nq = 4; nn = 2; break;
+    case EK_POT: nq = 5; nn = 2; break;
+    case EK_MOSFET: nq = 3; nn = 1; break;
+    case EK_MACAK: nq = 2; nn = 1; break;
+    case EK_JA: nq = 4; nn = 1; break;
+    default: nq = 0; nn = 0; break;
+    }
+}
+
+// pick the instantiated shape a model runs in: exact match first, else the cheapest
+// (least padded work) shape that contains it
+inline bool choose_shape(const Dims &d, Dims &out) {
+    const auto &list = shape_list();
+    long best = -1;
+    for (const Dims &s : list) {
+        if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny) {
+            out = s;
+            return true;
+        }
+        bool fits = d.nn <= s.nn && d.np <= s.np && d.nx <= s.nx && d.nu <= s.nu && d.ny <= s.ny &&
+                    d.nq + (s.nn - d.nn) <= s.nq;
+        if (!fits) continue;
+        long cost = (long)s.nn * s.nn * s.nn + (long)s.nq * (s.nn + s.np) + (long)(s.nx + s.np + s.ny) * (s.nx + s.nu + s.nn);
+        if (best < 0 || cost < best) {
+            best = cost;
+            out = s;
+        }
+    }
+    return best >= 0;
+}
+
+inline void put(std::vector<double> &img, int off, int ld, const std::vector<double> &m, int r, int c) {
+    // copy an r x c column-major matrix into a column-major block with leading dim ld
+    for (int j = 0; j < c; ++j)
+        for (int i = 0; i < r; ++i) img[off + (size_t)j * ld + i] = m[(size_t)j * r + i];
+}
+
+inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Dims *force_shape = nullptr) {
+    if (m.subs.size() > 1) {
+        err = "models with more than one nonlinear sub-problem are not supported by the GPU path yet; "
+              "derive the model with decompose_nonlinearity=false";
+        return false;
+    }
+    Dims d{};
+    d.nx = m.nx; d.nu = m.nu; d.ny = m.ny;
+    const HostSub *s = m.subs.empty() ? nullptr : &m.subs[0];
+    if (s) { d.nn = s->nn; d.nq = s->nq; d.np = s->np; }
+    if (d.nn > MAX_NN || d.nq > MAX_NQ || d.np > MAX_NP || d.nx > MAX_NX || d.nu > MAX_NU || d.ny > MAX_NY) {
+        err = "model dimensions exceed the limits of the 16-lane kernel (nn<=16, nq<=32, np<=16, nx<=32, nu<=8, ny<=16)";
+        return false;
+    }
+    Dims S{};
+    if (force_shape) {
+        S = *force_shape;
+        if (!(d.nn <= S.nn && d.np <= S.np && d.nx <= S.nx && d.nu <= S.nu && d.ny <= S.ny &&
+              d.nq + (S.nn - d.nn) <= S.nq)) {
+            err = "model does not fit the batch's kernel shape";
+            return false;
+        }
+    } else if (!choose_shape(d, S)) {
+        err = "no instantiated kernel shape contains this model";
+        return false;
+    }
+    P.shape = S;
+    P.actual = d;
+    const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny);
+    P.image.assign(L.total, 0.0);
+    put(P.image, L.a, S.nx, m.a, d.nx, d.nx);
+    put(P.image, L.b, S.nx, m.b, d.nx, d.nu);
+    put(P.image, L.x0, S.nx, m.x0, d.nx, 1);
+    put(P.image, L.dy, S.ny, m.dy, d.ny, d.nx);
+    put(P.image, L.ey, S.ny, m.ey, d.ny, d.nu);
+    put(P.image, L.y0, S.ny, m.y0, d.ny, 1);
+    P.rowc.assign((size_t)ROWC * GROUP, 0.0);
+    P.rowi.assign((size_t)ROWI * GROUP, 0);
+    P.init_state.assign((size_t)S.nx + S.np + S.nn, 0.0);
+    P.nterms = 2; P.has_bjt = 0; P.rare_kinds = 0;
+    if (s) {
+        put(P.image, L.c, S.nx, m.c, d.nx, d.nn);
+        put(P.image, L.fy, S.ny, m.fy, d.ny, d.nn);
+        put(P.image, L.dq, S.np, s->dq, d.np, d.nx);
+        put(P.image, L.eq, S.np, s->eq, d.np, d.nu);
+        put(P.image, L.pexp, S.nq, s->pexp, d.nq, d.np);
+        put(P.image, L.fq, S.nq, s->fq, d.nq, d.nn);
+        put(P.image, L.q0, S.nq, s->q0, d.nq, 1);
+        for (int i = 0; i < d.nn; ++i) P.init_state[S.nx + S.np + i] = s->init_z[i];
+        auto RC = [&](int row, int c) -> double & { return P.rowc[(size_t)c * GROUP + row]; };
+        auto RI = [&](int row, int w) -> int & { return P.rowi[(size_t)w * GROUP + row]; };
+        for (size_t e = 0; e < s->kind.size(); ++e) {
+            int kind = s->kind[e], knq, knn;
+            kind_shape(kind, knq, knn);
+            const double *p = &s->par[e * MAX_ELEM_PAR];
+            for (int er = 0; er < knn; ++er) {
+                int row = s->roff[e] + er;
+                if (row >= d.nn) { err = "element table row out of range"; return false; }
+                RI(row, 0) = kind;  // RowKind numbering == element kind numbering
+                RI(row, 1) = er;
+                RI(row, 2) = s->qoff[e];
+                int flags = 0;
+                switch (kind) {
+                case EK_DIODE: {  // src/elements.jl:238-244
+                    double is = p[0], eta = p[1];
+                    RC(row, 0) = 1 / (25e-3 * eta);
+                    RC(row, 1) = is;
+                    RC(row, 2) = is / (25e-3 * eta);
+                    break;
+                }
+                case EK_BJT: {  // src/elements.jl:323-401
+                    double ise = p[0], isc = p[1], etae = p[2], etac = p[3], bf = p[4], br = p[5], ile = p[6],
+                           ilc = p[7], etael = p[8], etacl = p[9], vaf = p[10], var = p[11], ikf = p[12], ikr = p[13];
+                    RC(row, 0) = 1 / (25e-3 * etae);
+                    RC(row, 1) = 1 / (25e-3 * etac);
+                    RC(row, 2) = bf / (1 + bf) * ise;
+                    RC(row, 3) = br / (1 + br) * isc;
+                    RC(row, 4) = bf / (1 + bf) * ise / (25e-3 * etae);
+                    RC(row, 5) = br / (1 + br) * isc / (25e-3 * etac);
+                    RC(row, 6) = 1 / bf;
+                    RC(row, 7) = 1 / br;
+                    RC(row, 8) = 1 / var;
+                    RC(row, 9) = 1 / vaf;
+                    RC(row, 10) = 1 / ikf;
+                    RC(row, 11) = 1 / ikr;
+                    RC(row, 12) = ile;
+                    RC(row, 13) = ilc;
+                    RC(row, 14) = 1 / (25e-3 * etael);
+                    RC(row, 15) = 1 / (25e-3 * etacl);
+                    RC(row, 16) = ile / (25e-3 * etae);  // sic: the reference uses eta_e here (:384)
+                    RC(row, 17) = ilc / (25e-3 * etac);  // and eta_c here (:395)
+                    RC(row, 18) = -1 / var;
+                    RC(row, 19) = -1 / vaf;
+                    if (!(std::isinf(var) && std::isinf(vaf))) flags |= RF_EARLY;
+                    if (!(std::isinf(ikf) && std::isinf(ikr))) flags |= RF_KNEE;
+                    if (ile != 0) flags |= RF_ILE;
+                    if (ilc != 0) flags |= RF_ILC;
+                    if (etael != etae) flags |= RF_ETAEL;
+                    if (etacl != etac) flags |= RF_ETACL;
+                    P.has_bjt = 1;
+                    if (P.nterms < 3) P.nterms = 3;
+                    if (flags & (RF_ILE | RF_ILC)) P.rare_kinds |= 0;  // handled inside the BJT branch
+                    break;
+                }
+                case EK_POT:  // src/elements.jl:25-30
+                    RC(row, 0) = p[0];
+                    if (P.nterms < 3) P.nterms = 3;
+                    break;
+                case EK_MOSFET: {  // src/elements.jl:444-447
+                    for (int c = 0; c < 12; ++c) RC(row, c) = p[c];
+                    int nvt = (int)p[2], na = (int)p[7];
+                    for (int k = 1; k < nvt; ++k) RC(row, 12 + k - 1) = p[3 + k] * k;
+                    for (int k = 1; k < na; ++k) RC(row, 15 + k - 1) = p[8 + k] * k;
+                    P.rare_kinds = 1;
+                    if (P.nterms < 3) P.nterms = 3;
+                    break;
+                }
+                case EK_MACAK:  // src/elements.jl:540-546
+                    RC(row, 0) = p[0];
+                    RC(row, 1) = p[1];
+                    RC(row, 2) = p[0] / p[1];
+                    P.rare_kinds = 1;
+                    break;
+                case EK_JA: {  // src/elements.jl:107-129
+                    double Ms = p[0], a = p[1], alpha = p[2], c = p[3];
+                    for (int k = 0; k < 5; ++k) RC(row, k) = p[k];
+                    RC(row, 5) = 1e-4 / Ms;
+                    RC(row, 6) = c * Ms / a;
+                    RC(row, 7) = c * Ms / a * alpha;
+                    P.rare_kinds = 1;
+                    P.nterms = 4;
+                    break;
+                }
+                default:
+                    err = "unknown element kind";
+                    return false;
+                }
+                RI(row, 3) = flags;
+            }
+        }
+    }
+    // shape padding: extra unknowns z_pad with the trivial equation q_pad = z_pad = 0
+    for (int r = d.nn; r < S.nn; ++r) {
+        int qrow = d.nq + (r - d.nn);
+        P.image[L.fq + (size_t)r * S.nq + qrow] = 1.0;
+        P.rowi[0 * GROUP + r] = RK_PAD;
+        P.rowi[2 * GROUP + r] = qrow;
+    }
+    return true;
+}
+
+}  // namespace acme

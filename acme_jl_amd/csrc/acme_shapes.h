@@ -1,0 +1,21 @@
+// acme_shapes.h -- the (NN,NQ,NP,NX,NU,NY) shapes the kernel is instantiated for.
+//
+// Loop bounds, DPP lane selects and register-array subscripts are compile-time constants
+// (the reference gets the same effect from Julia specialising StaticArrays sizes per
+// circuit).  A model whose dimensions are not listed is zero-padded on the host to the
+// cheapest listed shape that contains it (see acme_pack.h); the first five are the exact
+// shapes of the BASELINE circuits (dimensions verified by tests/test_frontend.py against
+// the np(model,k) pins of test/runtests.jl:699,724,734,744,777).
+#pragma once
+// clang-format off
+#define ACME_SHAPES(X)                                                                     \
+    X( 2,  4,  1,  1, 1, 1)  /* examples/diodeclipper.jl                                */ \
+    X( 7, 14,  5, 11, 1, 1)  /* examples/superover.jl, fixed potentiometers             */ \
+    X(13, 29, 11, 11, 4, 1)  /* examples/superover.jl, drive/tone/level as inputs       */ \
+    X( 2,  4,  2,  3, 1, 1)  /* examples/birdie.jl, fixed vol                           */ \
+    X( 4,  9,  3,  3, 2, 1)  /* examples/birdie.jl, vol as input                        */ \
+    X( 0,  0,  0, 32, 2, 2)  /* linear models (no nonlinear sub-problem)                */ \
+    X( 4, 12,  4,  4, 2, 4)  /* generic small                                           */ \
+    X( 8, 24,  8, 16, 4, 4)  /* generic medium                                          */ \
+    X(16, 32, 16, 32, 8, 8)  /* generic large                                           */
+// clang-format on

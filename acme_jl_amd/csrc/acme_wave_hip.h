@@ -1,0 +1,61 @@
+// acme_wave_hip.h -- gfx950 (CDNA4, wave64) cross-lane primitives used by the kernels.
+//
+// One circuit instance lives in one DPP row (16 lanes).  Row-local broadcasts and
+// rotations are DPP modifiers on v_mov_b32 (row_newbcast / row_ror): no LDS traffic, no
+// address VGPRs.  Only the dynamic row interchange of the pivoting LU needs ds_bpermute.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define ACME_DEV __device__ __forceinline__
+
+namespace wv {
+
+ACME_DEV int tid() { return (int)threadIdx.x; }
+ACME_DEV int bid() { return (int)blockIdx.x; }
+ACME_DEV void block_sync() { __syncthreads(); }
+// orders this wave's LDS writes before its later LDS reads (one wave executes DS ops in
+// order; this only stops the compiler from reordering across it)
+ACME_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                             __builtin_amdgcn_wave_barrier(); }
+
+template <int CTRL> ACME_DEV int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> ACME_DEV double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = dpp_i<CTRL>(lo);
+    hi = dpp_i<CTRL>(hi);
+    return __hiloint2double(hi, lo);
+}
+// value of lane K of each 16-lane row, in every lane of that row (row_newbcast:K)
+template <int K> ACME_DEV double bcast16(double v) { return dpp_d<0x150 + K>(v); }
+template <int K> ACME_DEV int bcast16(int v) { return dpp_i<0x150 + K>(v); }
+// rotate right by R within each 16-lane row (row_ror:R)
+template <int R> ACME_DEV double ror16(double v) { return dpp_d<0x120 + R>(v); }
+
+// max over the 16 lanes of each row, result in every lane (4 rotate+max steps)
+ACME_DEV double allmax16(double v) {
+    v = fmax(v, ror16<8>(v));
+    v = fmax(v, ror16<4>(v));
+    v = fmax(v, ror16<2>(v));
+    v = fmax(v, ror16<1>(v));
+    return v;
+}
+
+// arbitrary gather inside a row: value of lane (row base + src) -- ds_bpermute_b32
+ACME_DEV int shfl16(int v, int src) {
+    int lane = (int)(threadIdx.x & 63);
+    return __builtin_amdgcn_ds_bpermute(((lane & ~15) + src) << 2, v);
+}
+ACME_DEV double shfl16(double v, int src) {
+    int lane = (int)(threadIdx.x & 63);
+    int addr = ((lane & ~15) + src) << 2;
+    int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+ACME_DEV unsigned long long ballot(bool p) { return __ballot(p); }
+ACME_DEV int ffs32(int v) { return __ffs(v); }
+
+}  // namespace wv

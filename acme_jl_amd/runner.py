@@ -1,0 +1,346 @@
+"""ModelRunner / run: the host-side mirror of the reference's runner API over the C ABI.
+
+Reference interface mirrored (src/ACME.jl):
+  * ``ModelRunner(model, showprogress)`` ............ :570-604
+  * ``run!(runner, u)`` / ``run!(runner, y, u)`` ..... :619-664 (+ ``checkiosizes`` :625-635)
+  * ``run!(model, u)`` ............................... :567-568
+  * failure policy of ``step!`` ....................... :688-694
+  * ``set_resabstol!`` / extrapolation origin ......... src/solvers.jl:181-198
+
+The difference to the reference is the batch axis: one runner advances ``n_instances``
+independent copies of the circuit in lock step on one GPU.  All compute happens in
+``libacme_hip.so`` (hand-written HIP for gfx950).  There is NO CPU fallback: if the
+library or a GPU is missing, constructing a runner raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+
+from .model import SOLVER_IDS, CachingHomotopySolver, DiscreteModel
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libacme_hip.so")
+
+ACME_MEM_HOST, ACME_MEM_DEVICE = 0, 1
+
+
+class DimensionMismatch(ValueError):
+    """Julia's DimensionMismatch (src/ACME.jl:625-635)."""
+
+
+class AcmeError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("solver", C.c_int), ("tol", C.c_double), ("maxiter", C.c_int),
+                ("device", C.c_int), ("per_instance_matrices", C.c_int)]
+
+
+class Report(C.Structure):
+    _fields_ = [("n_warn", C.c_longlong), ("first_nonconverged", C.c_longlong),
+                ("first_nonfinite", C.c_longlong), ("iters_total", C.c_longlong),
+                ("iters_max", C.c_longlong)]
+
+
+# every symbol include/acme_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "acme_last_error", "acme_device_count", "acme_default_options", "acme_model_create",
+    "acme_model_add_subproblem", "acme_model_destroy", "acme_model_kernel_shape",
+    "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
+    "acme_batch_last_kernel_ms", "acme_batch_get_report", "acme_batch_reset_report",
+    "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
+]
+
+
+class Library:
+    """ctypes binding of one shared library implementing include/acme_hip.h."""
+
+    def __init__(self, path=DEFAULT_LIBRARY):
+        if not os.path.exists(path):
+            raise AcmeError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                " (hipcc --offload-arch=gfx950).  acme_jl_amd has no CPU fallback.")
+        self.path = path
+        L = self.L = C.CDLL(path)
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.acme_last_error.restype = C.c_char_p
+        L.acme_device_count.restype = C.c_int
+        L.acme_default_options.argtypes = [C.POINTER(Options)]
+        L.acme_model_create.argtypes = [C.c_int] * 4 + [dp] * 8 + [C.POINTER(vp)]
+        L.acme_model_add_subproblem.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [dp] * 7 + \
+            [C.c_int, ip, ip, ip, dp]
+        L.acme_model_destroy.argtypes = [vp]
+        L.acme_model_destroy.restype = None
+        L.acme_model_kernel_shape.argtypes = [vp, ip]
+        L.acme_batch_create.argtypes = [vp, C.c_longlong, C.POINTER(Options), C.POINTER(vp)]
+        L.acme_batch_destroy.argtypes = [vp]
+        L.acme_batch_destroy.restype = None
+        L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
+        L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
+        L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.acme_batch_get_report.argtypes = [vp, C.POINTER(Report)]
+        L.acme_batch_reset_report.argtypes = [vp]
+        L.acme_batch_set_resabstol.argtypes = [vp, C.c_double]
+        L.acme_batch_get_state.argtypes = [vp, dp, dp, dp]
+        L.acme_batch_set_state.argtypes = [vp, dp, dp, dp]
+
+    def check(self, rc):
+        if rc < 0:
+            raise AcmeError(self.L.acme_last_error().decode())
+        return rc
+
+    def device_count(self):
+        return self.L.acme_device_count()
+
+
+_DEFAULT = None
+
+
+def default_library():
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Library(DEFAULT_LIBRARY)
+    return _DEFAULT
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _fa(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+class _ModelHandle:
+    """acme_model* built from a DiscreteModel."""
+
+    def __init__(self, lib, model):
+        self.lib = lib
+        h = C.c_void_p()
+        keep = [_fa(model.a), _fa(model.b), _fa(model.c), _fa(model.x0), _fa(model.dy),
+                _fa(model.ey), _fa(model.fy), _fa(model.y0)]
+        lib.check(lib.L.acme_model_create(model.nx, model.nu, model.ny, model.nn_total,
+                                          *[_dp(k) for k in keep], C.byref(h)))
+        self.h = h
+        for s in model.subs:
+            kind, qoff, roff, par = s.elem_arrays()
+            mats = [_fa(s.pexp), _fa(s.dq), _fa(s.eq), _fa(s.fqprev), _fa(s.fq), _fa(s.q0),
+                    _fa(s.init_z)]
+            par = np.ascontiguousarray(par)
+            lib.check(lib.L.acme_model_add_subproblem(
+                h, s.nn, s.nq, s.np, *[_dp(k) for k in mats], len(s.table), _ip(kind),
+                _ip(qoff), _ip(roff), _dp(par)))
+
+    def kernel_shape(self):
+        dims = (C.c_int * 6)()
+        self.lib.check(self.lib.L.acme_model_kernel_shape(self.h, dims))
+        return tuple(dims)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.L.acme_model_destroy(self.h)
+            self.h = None
+
+
+class ModelRunner:
+    """``ModelRunner(model, showprogress)`` for ``n_instances`` parallel copies of a model.
+
+    ``models``: optional list of ``n_instances`` DiscreteModels with the same circuit
+    topology but different component values (per-instance matrices, e.g. Monte-Carlo
+    component tolerances); the element tables must be identical.
+    """
+
+    def __init__(self, model, n_instances=1, showprogress=False, device=None, models=None,
+                 lib=None):
+        if not isinstance(model, DiscreteModel):
+            raise TypeError("model must be a DiscreteModel")
+        if model.solver == CachingHomotopySolver:
+            raise AcmeError(
+                "CachingSolver is not available on the GPU path (per-stream unbounded k-d tree, "
+                "only changes Newton's start point); construct the model with "
+                "solver=HomotopySolver")
+        self.lib = lib or default_library()
+        if self.lib.device_count() <= 0:
+            raise AcmeError("no HIP device available; acme_jl_amd has no CPU fallback")
+        self.model = model
+        self.n = int(n_instances)
+        self.showprogress = showprogress   # accepted for API parity; progress is not shown
+        self._mh = _ModelHandle(self.lib, model)
+        o = Options()
+        self.lib.L.acme_default_options(C.byref(o))
+        o.solver = SOLVER_IDS[model.solver]
+        o.device = -1 if device is None else int(device)
+        o.per_instance_matrices = 1 if models is not None else 0
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.acme_batch_create(self._mh.h, self.n, C.byref(o), C.byref(h)))
+        self.h = h
+        self._warned = 0
+        if models is not None:
+            self.set_models(0, models)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.L.acme_batch_destroy(self.h)
+            self.h = None
+
+    # ---- per-instance matrices ----------------------------------------------------------
+    def set_models(self, first, models):
+        hs = [_ModelHandle(self.lib, m) for m in models]
+        arr = (C.c_void_p * len(hs))(*[m.h for m in hs])
+        self.lib.check(self.lib.L.acme_batch_set_matrices(self.h, first, len(hs), arr))
+
+    # ---- run! ---------------------------------------------------------------------------
+    def _check_io(self, u_rows, y_rows, ucols, ycols):
+        m = self.model
+        if u_rows != m.nu:
+            raise DimensionMismatch(f"input matrix has {u_rows} rows, but model has {m.nu} inputs")
+        if y_rows != m.ny:
+            raise DimensionMismatch(f"output matrix has {y_rows} rows, but model has {m.ny} outputs")
+        if ucols != ycols:
+            raise DimensionMismatch(
+                f"input matrix has {ucols} columns, output matrix has {ycols} columns")
+
+    def run(self, u, y=None, check=True):
+        """``run!(runner, u)`` / ``run!(runner, y, u)`` with numpy arrays.
+
+        ``u``: (nu, T) for a single instance, else (N, nu, T); returns ``y`` of shape
+        (ny, T) resp. (N, ny, T).  Raises like the reference when an instance hits a
+        non-finite result and warns on convergence failures (unless ``check=False``)."""
+        m = self.model
+        u = np.asarray(u, dtype=np.float64)
+        single = u.ndim == 2
+        if single:
+            if self.n != 1:
+                raise DimensionMismatch("2-D input given to a runner with more than one instance")
+            u = u[None]
+        if u.ndim != 3 or u.shape[0] != self.n:
+            raise DimensionMismatch(f"input must have shape ({self.n}, {m.nu}, T)")
+        T = u.shape[2]
+        if y is not None:
+            y = np.asarray(y)
+            yy = y[None] if single else y
+            self._check_io(u.shape[1], yy.shape[1], T, yy.shape[2])
+        else:
+            self._check_io(u.shape[1], m.ny, T, T)
+        ub = np.ascontiguousarray(np.transpose(u, (0, 2, 1)))        # [N][T][nu]
+        yb = np.empty((self.n, T, m.ny), dtype=np.float64)
+        self.lib.check(self.lib.L.acme_batch_run(
+            self.h, ub.ctypes.data, yb.ctypes.data, T, ACME_MEM_HOST, None))
+        out = np.transpose(yb, (0, 2, 1))
+        if y is not None:
+            (y[None] if single else y)[...] = out
+        if check:
+            self.check()
+        if y is not None:
+            return y
+        return np.asfortranarray(out[0]) if single else np.ascontiguousarray(out)
+
+    def run_device(self, u_ptr, y_ptr, T, stream=None):
+        """Raw asynchronous launch: ``u_ptr``/``y_ptr`` are device addresses of
+        [N][T][nu] / [N][T][ny] float64 buffers on this runner's GPU."""
+        self.lib.check(self.lib.L.acme_batch_run(
+            self.h, C.c_void_p(u_ptr), C.c_void_p(y_ptr), int(T), ACME_MEM_DEVICE,
+            C.c_void_p(stream or 0)))
+
+    def run_torch(self, u, y=None):
+        """``u``: torch float64 CUDA tensor (N, T, nu); returns/fills ``y`` (N, T, ny).
+        Launches on torch's current stream, does not synchronise."""
+        import torch
+        m = self.model
+        if u.dtype != torch.float64 or not u.is_cuda or not u.is_contiguous():
+            raise TypeError("u must be a contiguous float64 CUDA tensor")
+        if u.dim() != 3 or u.shape[0] != self.n or u.shape[2] != m.nu:
+            raise DimensionMismatch(f"u must have shape ({self.n}, T, {m.nu})")
+        T = u.shape[1]
+        if y is None:
+            y = torch.empty((self.n, T, m.ny), dtype=torch.float64, device=u.device)
+        elif tuple(y.shape) != (self.n, T, m.ny) or y.dtype != torch.float64 or not y.is_contiguous():
+            raise DimensionMismatch(f"y must be a contiguous float64 tensor of shape ({self.n}, {T}, {m.ny})")
+        stream = torch.cuda.current_stream(u.device).cuda_stream
+        self.run_device(u.data_ptr(), y.data_ptr(), T, stream)
+        return y
+
+    # ---- reports, failure policy ----------------------------------------------------------
+    def reports(self):
+        r = (Report * self.n)()
+        self.lib.check(self.lib.L.acme_batch_get_report(self.h, r))
+        return r
+
+    def report_arrays(self):
+        r = self.reports()
+        a = np.frombuffer(r, dtype=np.int64).reshape(self.n, 5).copy()
+        return dict(n_warn=a[:, 0], first_nonconverged=a[:, 1], first_nonfinite=a[:, 2],
+                    iters_total=a[:, 3], iters_max=a[:, 4])
+
+    def check(self):
+        """Apply step!'s policy (src/ACME.jl:688-694) to the accumulated reports."""
+        ra = self.report_arrays()
+        if (ra["first_nonfinite"] >= 0).any():
+            i = int(np.argmax(ra["first_nonfinite"] >= 0))
+            raise AcmeError("Failed to converge while solving non-linear equation, got non-finite "
+                            f"result. (instance {i}, sample {int(ra['first_nonfinite'][i])})")
+        nw = int(ra["n_warn"].sum())
+        if nw > self._warned:
+            warnings.warn("Failed to converge while solving non-linear equation.")
+            self._warned = nw
+
+    def reset_report(self):
+        self.lib.check(self.lib.L.acme_batch_reset_report(self.h))
+        self._warned = 0
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self.lib.check(self.lib.L.acme_batch_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- solver plugin surface ----------------------------------------------------------------
+    def set_resabstol(self, tol):
+        """``set_resabstol!`` (src/solvers.jl:181,262)."""
+        self.lib.check(self.lib.L.acme_batch_set_resabstol(self.h, float(tol)))
+
+    def get_state(self):
+        """(x, last_p, last_z): model.x and the extrapolation origin of every instance."""
+        m = self.model
+        s = m.subs[0] if m.subs else None
+        x = np.zeros((self.n, m.nx))
+        p = np.zeros((self.n, s.np if s else 0))
+        z = np.zeros((self.n, s.nn if s else 0))
+        self.lib.check(self.lib.L.acme_batch_get_state(self.h, _dp(x), _dp(p), _dp(z)))
+        return x, p, z
+
+    def set_state(self, x=None, p=None, z=None):
+        def prep(a, cols):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.n, cols)))
+            return a, _dp(a)
+        m = self.model
+        s = m.subs[0] if m.subs else None
+        xa, xp = prep(x, m.nx)
+        pa, pp = prep(p, s.np if s else 0)
+        za, zp = prep(z, s.nn if s else 0)
+        self.lib.check(self.lib.L.acme_batch_set_state(self.h, xp, pp, zp))
+
+    def kernel_shape(self):
+        return self._mh.kernel_shape()
+
+
+def run(model_or_runner, u, **kw):
+    """``run!(model, u)`` / ``run!(runner, u)`` (src/ACME.jl:567-568, 619-623).  The model's
+    state persists across calls: the runner is cached on the model object."""
+    if isinstance(model_or_runner, ModelRunner):
+        return model_or_runner.run(u, **kw)
+    model = model_or_runner
+    r = getattr(model, "_runner", None)
+    if r is None:
+        r = model._runner = ModelRunner(model, 1)
+    return r.run(u, **kw)

@@ -1,0 +1,144 @@
+/* acme_hip.h -- C ABI of libacme_hip.so: batched, MI355X-native run!(::DiscreteModel, u).
+ *
+ * This is the drop-in boundary for the one hot path of ACME.jl that this project
+ * accelerates.  Everything is plain C: pointers, sizes, integer status codes; no C++
+ * or torch types.  A maintainer binds it from Julia with `ccall` (see INTEGRATION.md for
+ * the glue that implements ModelRunner/run! on top of it); this repository's own host
+ * side binds it from Python with ctypes (acme_jl_amd/runner.py).
+ *
+ * Reference interfaces replaced (file:line relative to the ACME.jl tree):
+ *   DiscreteModel data .............................. src/ACME.jl:118-148
+ *   closures func/set_p/calc_Jp -> element table .... src/ACME.jl:176-194,236-252,
+ *                                                     src/circuit.jl:6-20,68-86
+ *   ModelRunner(model, showprogress) ................ src/ACME.jl:570-604
+ *   run!(runner, y, u) / step! ...................... src/ACME.jl:650-715
+ *   solver plugin contract (set_resabstol!, get/set_extrapolation_origin,
+ *     hasconverged, needediterations) ............... src/solvers.jl:181-205,262-302
+ *
+ * Conventions
+ *   * All matrices are column-major Float64, exactly Julia's Matrix{Float64} layout.
+ *   * A batch holds N independent instances of one model.  u is [N][T][nu] and y is
+ *     [N][T][ny] doubles, i.e. instance i's block is the reference's nu x T (ny x T)
+ *     column-major matrix, blocks back to back; a batch of one is bit-layout identical
+ *     to the reference's u and y.
+ *   * Every entry point returns ACME_OK (0) or a negative error code and never unwinds;
+ *     acme_last_error() returns a thread-local message for the last failure.
+ *   * Threading: handles are single-owner; distinct handles are independent.
+ *   * Failure semantics of step! (src/ACME.jl:688-694) are reported per instance in
+ *     acme_report: n_warn counts "Failed to converge" warnings; first_nonfinite >= 0 is
+ *     the sample at which the reference would have thrown -- that instance stops
+ *     advancing there (its x stays at that sample, y from there on is NaN).
+ */
+#ifndef ACME_HIP_H
+#define ACME_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACME_OK 0
+#define ACME_ERR_INVALID (-1)     /* bad argument / DimensionMismatch */
+#define ACME_ERR_UNSUPPORTED (-2) /* model does not fit the kernel (see message) */
+#define ACME_ERR_HIP (-3)         /* HIP runtime failure */
+#define ACME_ERR_NO_DEVICE (-4)   /* no usable GPU: the product path has no CPU fallback */
+
+/* element kinds of the nonlinear element table and their parameter vectors
+ * (ACME_MAX_ELEM_PAR doubles per element, unused entries zero) */
+#define ACME_KIND_DIODE 1  /* is, eta                                   src/elements.jl:236-245 */
+#define ACME_KIND_BJT 2    /* ise,isc,etae,etac,bf,br,ile,ilc,etael,etacl,vaf,var,ikf,ikr
+                                                                       src/elements.jl:309-406 */
+#define ACME_KIND_POT 3    /* r                                         src/elements.jl:20-31   */
+#define ACME_KIND_MOSFET 4 /* polarity,lambda,nvt,vt[4],nalpha,alpha[4] src/elements.jl:436-481 */
+#define ACME_KIND_MACAK 5  /* gain, scale                               src/elements.jl:536-551 */
+#define ACME_KIND_JA 6     /* Ms,a,alpha,c,k                            src/elements.jl:100-135 */
+#define ACME_MAX_ELEM_PAR 16
+
+/* solver selection = third positional argument of DiscreteModel (src/ACME.jl:150) */
+#define ACME_SOLVER_SIMPLE 0   /* SimpleSolver                  src/solvers.jl:151-236 */
+#define ACME_SOLVER_HOMOTOPY 1 /* HomotopySolver{SimpleSolver}  src/solvers.jl:247-302 */
+
+/* where u / y live */
+#define ACME_MEM_HOST 0
+#define ACME_MEM_DEVICE 1
+
+typedef struct acme_model acme_model;
+typedef struct acme_batch acme_batch;
+
+typedef struct {
+    int solver;    /* ACME_SOLVER_*; default HOMOTOPY */
+    double tol;    /* residual max-abs tolerance, default 1e-10 (src/solvers.jl:175) */
+    int maxiter;   /* Newton iterations per base solve, default 500 (src/solvers.jl:207) */
+    int device;    /* HIP device ordinal, -1 = current device */
+    int per_instance_matrices; /* 0: all instances share the model's matrices;
+                                  1: every instance has its own (acme_batch_set_matrices) */
+} acme_options;
+
+typedef struct {
+    long long n_warn;             /* "Failed to converge" warnings so far            */
+    long long first_nonconverged; /* 0-based sample of the first warning, -1 if none */
+    long long first_nonfinite;    /* 0-based sample of the fatal error, -1 if none   */
+    long long iters_total;        /* sum of needediterations over all samples        */
+    long long iters_max;          /* max needediterations of one sample              */
+} acme_report;
+
+const char *acme_last_error(void);
+/* number of visible HIP devices (0 if none / runtime unavailable) */
+int acme_device_count(void);
+void acme_default_options(acme_options *opts);
+
+/* ---- model: the data of struct DiscreteModel (src/ACME.jl:118-148) ------------------ */
+int acme_model_create(int nx, int nu, int ny, int nn_total, const double *a, const double *b,
+                      const double *c, const double *x0, const double *dy, const double *ey,
+                      const double *fy, const double *y0, acme_model **out);
+/* one nonlinear sub-problem: pexps/dqs/eqs/fqprevs/fqs/q0s[idx] (src/ACME.jl:123-128), the
+ * initial extrapolation origin z (p = 0; src/ACME.jl:253-259) and the element table in
+ * CircuitNLFunc order (src/circuit.jl:68-86); elem_par is n_elems x ACME_MAX_ELEM_PAR
+ * row-major */
+int acme_model_add_subproblem(acme_model *m, int nn, int nq, int np, const double *pexp,
+                              const double *dq, const double *eq, const double *fqprev,
+                              const double *fq, const double *q0, const double *init_z,
+                              int n_elems, const int *elem_kind, const int *elem_qoff,
+                              const int *elem_roff, const double *elem_par);
+void acme_model_destroy(acme_model *m);
+/* dims = {nn, nq, np, nx, nu, ny} of the instantiated kernel shape the model runs in */
+int acme_model_kernel_shape(const acme_model *m, int dims[6]);
+
+/* ---- batch: N instances + their device-resident mutable state ----------------------- */
+/* state starts like a fresh DiscreteModel: x = 0 (src/ACME.jl:145), origin (0, init_z) */
+int acme_batch_create(const acme_model *m, long long n_instances, const acme_options *opts,
+                      acme_batch **out);
+void acme_batch_destroy(acme_batch *b);
+
+/* per-instance matrices (Monte-Carlo component tolerances): instance i uses the matrices
+ * of models[i]; all models must have the dimensions and element table of the batch's
+ * model.  Only valid for batches created with per_instance_matrices = 1. */
+int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
+                            const acme_model *const *models);
+
+/* run!(runner, y, u): advance every instance by T samples (src/ACME.jl:650-664).
+ * mem = ACME_MEM_HOST: u/y are host buffers (staged through HBM by the library);
+ * mem = ACME_MEM_DEVICE: u/y are device pointers on the batch's device and `stream` is the
+ * hipStream_t to launch on (NULL = default stream); the call is then asynchronous. */
+int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
+                   void *stream);
+
+/* milliseconds the last acme_batch_run kernel took on the device (HIP events recorded on
+ * the launch stream); synchronises with that launch */
+int acme_batch_last_kernel_ms(acme_batch *b, float *ms);
+
+/* per-instance reports, reports[n_instances]; synchronises */
+int acme_batch_get_report(acme_batch *b, acme_report *reports);
+int acme_batch_reset_report(acme_batch *b);
+
+/* set_resabstol! (src/solvers.jl:181,262) */
+int acme_batch_set_resabstol(acme_batch *b, double tol);
+
+/* model.x and get/set_extrapolation_origin (src/solvers.jl:183-198) for all instances:
+ * x is [N][nx], p is [N][np], z is [N][nn] (sub-problem 0); NULL pointers are skipped */
+int acme_batch_get_state(acme_batch *b, double *x, double *p, double *z);
+int acme_batch_set_state(acme_batch *b, const double *x, const double *p, const double *z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+// acme_emu.cpp -- the C ABI of include/acme_hip.h on top of the CPU wave emulator.
+//
+// TEST INFRASTRUCTURE ONLY (see wave_emu.h).  Shares acme_api.inc, acme_pack.h and
+// acme_kernel.h with the HIP library; only the device backend differs.  "Device memory" is
+// host memory, a "launch" runs the blocks one after another on fibers.
+#include "wave_emu.h"
+
+#include <chrono>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <sys/mman.h>
+
+#include "../../include/acme_hip.h"
+#include "../../acme_jl_amd/csrc/acme_kernel.h"
+#include "../../acme_jl_amd/csrc/acme_pack.h"
+
+using namespace acme;
+
+namespace emu {
+BlockCtx *g_blk = nullptr;
+int g_debug = getenv("ACME_EMU_DEBUG") ? atoi(getenv("ACME_EMU_DEBUG")) : 0;
+
+asm(R"(
+.text
+.globl acme_emu_switch
+.type acme_emu_switch,@function
+acme_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size acme_emu_switch,.-acme_emu_switch
+)");
+
+static void fiber_main() {
+    BlockCtx *b = g_blk;
+    b->entry(b->entry_arg);
+    // exit: this lane leaves its wave and the block
+    int me = b->cur;
+    Fiber &f = b->fibers[me];
+    f.done = true;
+    WaveSync &ws = b->waves[me >> 6];
+    --ws.alive;
+    --b->block_alive;
+    if (ws.alive > 0 && ws.arrived == ws.alive) {  // the others were waiting for this lane only
+        ws.arrived = 0;
+        ++ws.generation;
+    }
+    if (b->block_alive > 0 && b->block_arrived == b->block_alive) {
+        b->block_arrived = 0;
+        ++b->block_generation;
+    }
+    for (;;) {  // hand control to any live fiber, or back to the scheduler
+        int nxt = -1;
+        for (int k = 1; k <= BLOCK; ++k) {
+            int c = (me + k) % BLOCK;
+            if (!b->fibers[c].done) { nxt = c; break; }
+        }
+        void *dummy;
+        if (nxt < 0) acme_emu_switch(&dummy, b->sched_sp);
+        b->cur = nxt;
+        acme_emu_switch(&dummy, b->fibers[nxt].sp);
+    }
+}
+
+static char *g_stacks = nullptr;
+
+void run_block(int bid, void (*entry)(void *), void *arg) {
+    if (!g_stacks) {
+        g_stacks = (char *)mmap(nullptr, STACK_BYTES * BLOCK, PROT_READ | PROT_WRITE,
+                                MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (g_stacks == (char *)MAP_FAILED) die("mmap of fiber stacks failed");
+    }
+    auto blk = std::make_unique<BlockCtx>();
+    BlockCtx *b = blk.get();
+    b->bid = bid;
+    b->entry = entry;
+    b->entry_arg = arg;
+    for (int t = 0; t < BLOCK; ++t) {
+        Fiber &f = b->fibers[t];
+        f.tid = t;
+        f.stack = g_stacks + (size_t)t * STACK_BYTES;
+        uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+        void **sp = (void **)top;
+        *--sp = nullptr;               // fake return address of fiber_main (never used)
+        *--sp = (void *)&fiber_main;   // `ret` target of the first switch
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        f.sp = (void *)sp;
+    }
+    g_blk = b;
+    b->cur = 0;
+    acme_emu_switch(&b->sched_sp, b->fibers[0].sp);
+    g_blk = nullptr;
+}
+}  // namespace emu
+
+// ------------------------------------------------------------------------------------------
+// kernel table
+// ------------------------------------------------------------------------------------------
+struct KernelEntry {
+    Dims d;
+    const void *fn;
+    int lds_shared, lds_per_inst, state;
+    int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
+};
+
+struct LaunchCtx {
+    const KArgs *A;
+    double *lds;
+};
+
+template <class S> static void fiber_entry(void *p) {
+    LaunchCtx *c = (LaunchCtx *)p;
+    wave_main<S>(*c->A, c->lds);
+}
+
+template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
+    std::vector<double> lds(lds_bytes / sizeof(double) + 64);
+    LaunchCtx c{&A, lds.data()};
+    for (unsigned b = 0; b < grid; ++b) {
+        // poison the LDS with NaNs: a kernel reading uninitialised LDS into a result shows up
+        for (auto &v : lds) v = std::nan("");
+        emu::run_block((int)b, &fiber_entry<S>, &c);
+    }
+    return 0;
+}
+
+static const std::vector<KernelEntry> &kernel_table() {
+    static const std::vector<KernelEntry> t = {
+#define ACME_X(nn, nq, np, nx, nu, ny)                                                              \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny}, nullptr, Shape<nn, nq, np, nx, nu, ny>::lds_doubles(false), \
+                Shape<nn, nq, np, nx, nu, ny>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny>::STATE,  \
+                &launch_shape<Shape<nn, nq, np, nx, nu, ny>>},
+        ACME_EMU_SHAPES(ACME_X)
+#undef ACME_X
+    };
+    return t;
+}
+
+static const KernelEntry *find_kernel(const Dims &d) {
+    for (const auto &k : kernel_table())
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny)
+            return &k;
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-memory "device" backend
+// ------------------------------------------------------------------------------------------
+namespace be {
+using stream_t = void *;
+struct Ev { std::chrono::steady_clock::time_point t; };
+using event_t = Ev *;
+static inline const char *err_string(int) { return "emulator error"; }
+static inline int device_count(int *n) { *n = 1; return 0; }
+static inline int set_device(int) { return 0; }
+static inline int get_device(int *d) { *d = 0; return 0; }
+static inline int set_max_lds(const void *, int) { return 0; }
+static inline int dmalloc(void **p, size_t n) { *p = malloc(n ? n : 8); return *p ? 0 : 1; }
+static inline int dfree(void *p) { free(p); return 0; }
+static inline int copy_h2d(void *d, const void *s, size_t n) { memcpy(d, s, n); return 0; }
+static inline int copy_d2h(void *d, const void *s, size_t n) { memcpy(d, s, n); return 0; }
+static inline int copy_h2d_async(void *d, const void *s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+static inline int copy_d2h_async(void *d, const void *s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+static inline int device_sync() { return 0; }
+static inline int stream_sync(stream_t) { return 0; }
+static inline int event_create(event_t *e) { *e = new Ev(); return 0; }
+static inline int event_destroy(event_t e) { delete e; return 0; }
+static inline int event_record(event_t e, stream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
+static inline int event_sync(event_t) { return 0; }
+static inline int event_elapsed(float *ms, event_t a, event_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return 0;
+}
+}  // namespace be
+
+#include "../../acme_jl_amd/csrc/acme_api.inc"

@@ -1,0 +1,196 @@
+// wave_emu.h -- CPU wave emulator for the kernels of acme_jl_amd/csrc/acme_kernel.h.
+//
+// TEST INFRASTRUCTURE ONLY.  Lets the GPU-less unit tests execute the *unmodified* device
+// source: every GPU thread of a 256-thread block becomes a fiber (hand-rolled x86-64
+// context switch) on one OS thread, and the cross-lane primitives of namespace wv
+// (row_newbcast / row_ror / ds_bpermute / ballot) are implemented as exchanges through a
+// per-wave buffer with a wave-wide rendezvous.  The rendezvous also checks that every lane
+// of the wave reaches the same cross-lane call site -- i.e. that cross-lane operations only
+// occur in wave-uniform control flow, which the DPP-based kernel relies on.
+// It is never linked into libacme_hip.so and never loaded by the acme_jl_amd package.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define ACME_DEV inline
+#define ACME_LAMBDA
+#define ACME_HD
+#define ACME_DBG(fmt, ...) do { if (emu::g_debug) fprintf(stderr, fmt "\n", __VA_ARGS__); } while (0)
+
+namespace emu {
+
+constexpr int BLOCK = 256;
+constexpr size_t STACK_BYTES = 512 * 1024;
+
+struct Fiber {
+    void *sp = nullptr;
+    char *stack = nullptr;
+    int tid = 0;
+    bool done = false;
+    unsigned parity = 0;  // exchange-buffer parity, identical across a wave by construction
+};
+
+struct WaveSync {
+    int arrived = 0;
+    unsigned generation = 0;
+    int alive = 64;
+    // double-buffered exchange slots
+    uint64_t slot[2][64];
+    int site[2][64];
+};
+
+struct BlockCtx {
+    Fiber fibers[BLOCK];
+    WaveSync waves[BLOCK / 64];
+    int block_arrived = 0;
+    unsigned block_generation = 0;
+    int block_alive = BLOCK;
+    int bid = 0;
+    int cur = 0;
+    void *sched_sp = nullptr;
+    void (*entry)(void *) = nullptr;
+    void *entry_arg = nullptr;
+};
+
+extern BlockCtx *g_blk;
+extern int g_debug;
+extern "C" void acme_emu_switch(void **save_sp, void *load_sp);
+
+[[noreturn]] inline void die(const char *msg) {
+    fprintf(stderr, "wave emulator: %s\n", msg);
+    abort();
+}
+
+inline void switch_to(int next) {
+    BlockCtx *b = g_blk;
+    int prev = b->cur;
+    if (next == prev) return;
+    b->cur = next;
+    acme_emu_switch(&b->fibers[prev].sp, b->fibers[next].sp);
+}
+
+// rendezvous of all live lanes of the calling lane's wave
+inline void wave_sync() {
+    BlockCtx *b = g_blk;
+    int me = b->cur, w = me >> 6;
+    WaveSync &ws = b->waves[w];
+    unsigned gen = ws.generation;
+    if (++ws.arrived == ws.alive) {
+        ws.arrived = 0;
+        ++ws.generation;
+        return;
+    }
+    int spins = 0;
+    while (ws.generation == gen) {
+        int nxt = me;
+        for (int k = 1; k <= 64; ++k) {
+            int c = (w << 6) + ((me + k) & 63);
+            if (!b->fibers[c].done) { nxt = c; break; }
+        }
+        if (nxt == me || ++spins > 100000) die("deadlock: cross-lane operation in divergent control flow");
+        switch_to(nxt);
+    }
+}
+
+inline void block_sync() {
+    BlockCtx *b = g_blk;
+    int me = b->cur;
+    unsigned gen = b->block_generation;
+    if (++b->block_arrived == b->block_alive) {
+        b->block_arrived = 0;
+        ++b->block_generation;
+        return;
+    }
+    int spins = 0;
+    while (b->block_generation == gen) {
+        int nxt = me;
+        for (int k = 1; k <= BLOCK; ++k) {
+            int c = (me + k) % BLOCK;
+            if (!b->fibers[c].done) { nxt = c; break; }
+        }
+        if (nxt == me || ++spins > 1000000) die("deadlock in block_sync");
+        switch_to(nxt);
+    }
+}
+
+// exchange: every lane publishes `v`, then reads the value published by lane `src`
+inline uint64_t exchange(uint64_t v, int src_lane, int site) {
+    BlockCtx *b = g_blk;
+    int me = b->cur, w = me >> 6, lane = me & 63;
+    Fiber &f = b->fibers[me];
+    unsigned par = f.parity & 1;
+    f.parity++;
+    WaveSync &ws = b->waves[w];
+    ws.slot[par][lane] = v;
+    ws.site[par][lane] = site;
+    wave_sync();
+    if (ws.site[par][src_lane] != site) die("lanes of one wave reached different cross-lane call sites");
+    return ws.slot[par][src_lane];
+}
+
+inline uint64_t ballot_bits(bool p, int site) {
+    BlockCtx *b = g_blk;
+    int me = b->cur, w = me >> 6, lane = me & 63;
+    Fiber &f = b->fibers[me];
+    unsigned par = f.parity & 1;
+    f.parity++;
+    WaveSync &ws = b->waves[w];
+    ws.slot[par][lane] = p ? 1 : 0;
+    ws.site[par][lane] = site;
+    wave_sync();
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) {
+        if (b->fibers[(w << 6) + l].done) continue;
+        if (ws.site[par][l] != site) die("ballot reached from different call sites");
+        if (ws.slot[par][l]) m |= (1ull << l);
+    }
+    return m;
+}
+
+inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+// run one block of `BLOCK` fibers, each executing entry(arg)
+void run_block(int bid, void (*entry)(void *), void *arg);
+
+}  // namespace emu
+
+namespace wv {
+ACME_DEV int tid() { return emu::g_blk->fibers[emu::g_blk->cur].tid; }
+ACME_DEV int bid() { return emu::g_blk->bid; }
+ACME_DEV void block_sync() { emu::block_sync(); }
+ACME_DEV void wave_fence() { emu::wave_sync(); }  // lanes run one after another here: LDS hand-offs need a rendezvous
+template <int K> ACME_DEV double bcast16(double v) {
+    int lane = tid() & 63;
+    return emu::u2d(emu::exchange(emu::d2u(v), (lane & ~15) + K, 100 + K));
+}
+template <int K> ACME_DEV int bcast16(int v) {
+    int lane = tid() & 63;
+    return (int)(int64_t)emu::exchange((uint64_t)(int64_t)v, (lane & ~15) + K, 200 + K);
+}
+template <int R> ACME_DEV double ror16(double v) {
+    int lane = tid() & 63;
+    // row_ror:R -- lane i receives the value of lane (i - R) mod 16 of its row
+    return emu::u2d(emu::exchange(emu::d2u(v), (lane & ~15) + ((lane - R) & 15), 300 + R));
+}
+ACME_DEV double allmax16(double v) {
+    v = fmax(v, ror16<8>(v));
+    v = fmax(v, ror16<4>(v));
+    v = fmax(v, ror16<2>(v));
+    v = fmax(v, ror16<1>(v));
+    return v;
+}
+ACME_DEV int shfl16(int v, int src) {
+    int lane = tid() & 63;
+    return (int)(int64_t)emu::exchange((uint64_t)(int64_t)v, (lane & ~15) + (src & 15), 400);
+}
+ACME_DEV double shfl16(double v, int src) {
+    int lane = tid() & 63;
+    return emu::u2d(emu::exchange(emu::d2u(v), (lane & ~15) + (src & 15), 401));
+}
+ACME_DEV unsigned long long ballot(bool p) { return emu::ballot_bits(p, 500); }
+ACME_DEV int ffs32(int v) { return __builtin_ffs(v); }
+}  // namespace wv
