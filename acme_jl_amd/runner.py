@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "acme_last_error", "acme_device_count", "acme_default_options", "acme_model_create",
     "acme_model_add_subproblem", "acme_model_destroy", "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
-    "acme_batch_last_kernel_ms", "acme_batch_get_report", "acme_batch_reset_report",
+    "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
 
@@ -83,6 +83,7 @@ class Library:
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.acme_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
         L.acme_batch_get_report.argtypes = [vp, C.POINTER(Report)]
         L.acme_batch_reset_report.argtypes = [vp]
         L.acme_batch_set_resabstol.argtypes = [vp, C.c_double]
@@ -301,6 +302,12 @@ class ModelRunner:
         ms = C.c_float()
         self.lib.check(self.lib.L.acme_batch_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def kernel_time(self, reset=False):
+        """(total ms, launches) of the kernels since the last reset, from HIP events."""
+        ms, n = C.c_double(), C.c_longlong()
+        self.lib.check(self.lib.L.acme_batch_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
 
     # ---- solver plugin surface ----------------------------------------------------------------
     def set_resabstol(self, tol):

@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the batched run! hot path on MI355X.
+
+Metric (BASELINE.json): circuit-instance*samples/sec, superover @ 44.1 kHz.
+Workload at N GPUs (weak scaling, 8192 instances per GPU): examples/superover.jl with the
+three potentiometers as inputs (shared model block, nn=13/nq=29/np=11), one instance per
+point of a drive x tone x level grid, 1 kHz unit sine, one "step" = 1 s of audio
+(44100 samples) for every instance.  Instances are independent: ranks shard the grid, the
+model block is broadcast once over RCCL before the timed region, and the only collective
+inside it is the all-reduce of the per-rank solver counters.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- algorithmic HBM bytes per launch / kernel time measured with HIP events
+  cpu_baseline -- the CPU oracle (a C restatement of the reference algorithm, NOT the Julia
+                  reference, which cannot run here) timed on the host cores of this box
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector peak (spec); not in the guide, AMD datasheet
+FS = 44100
+
+
+def grid_inputs(workload, rank, world, n_per_gpu, T):
+    """(model fixture name, numpy u-parameters) for this rank's shard of the sweep.
+
+    superover_grid: global grid drive(32*world) x tone(16) x level(16); level varies fastest
+    so that the 4 instances sharing a wavefront differ only in the output-stage pot (they
+    then need identical Newton iteration counts -> no intra-wave divergence).  drive stops
+    short of 1.0: at exactly 1.0 the pot's shorted leg has 0 Ohm, its current is
+    indeterminate and the variable-pot model is singular (the reference warns on every
+    sample there)."""
+    idx = np.arange(n_per_gpu) + rank * n_per_gpu
+    total = n_per_gpu * world
+    if workload == "superover_grid":
+        nd = total // 256
+        level = (idx % 16) / 15.0
+        tone = ((idx // 16) % 16) / 15.0
+        drive = (idx // 256) / float(nd)
+        pots = np.stack([drive, tone, level], axis=1)
+        return "superover_var", pots, 1.0
+    if workload == "diodeclipper_sweep":
+        amp = 10.0 ** (-2 + 3 * idx / max(total - 1, 1))
+        return "diodeclipper", None, amp
+    raise ValueError(workload)
+
+
+def make_u(torch, dev, model, pots, amp, n, T):
+    t = torch.arange(T, dtype=torch.float64, device=dev)
+    sig = torch.sin(2 * np.pi * 1000.0 / FS * t)
+    u = torch.empty((n, T, model.nu), dtype=torch.float64, device=dev)
+    if np.isscalar(amp):
+        u[:, :, 0] = amp * sig[None, :]
+    else:
+        u[:, :, 0] = torch.as_tensor(amp, dtype=torch.float64, device=dev)[:, None] * sig[None, :]
+    if pots is not None:
+        u[:, :, 1:] = torch.as_tensor(pots, dtype=torch.float64, device=dev)[:, None, :]
+    return u
+
+
+def algorithmic_bytes(model, n, T):
+    """8*(nu+ny) bytes per instance*sample + per-launch state/model traffic."""
+    s = model.subs[0] if model.subs else None
+    state = model.nx + (s.np + s.nn if s else 0)
+    per_sample = 8 * (model.nu + model.ny)
+    return n * T * per_sample + n * 2 * 8 * state
+
+
+def algorithmic_flops(model, iters_per_sample):
+    """SURVEY.md 8(d) flop model (sparse-aware), K = measured Newton evaluations/sample."""
+    s = model.subs[0]
+    nn, nq, np_, nx, nu, ny = s.nn, s.nq, s.np, model.nx, model.nu, model.ny
+    nnz = sum({1: 2, 2: 6, 3: 6, 4: 3, 5: 2, 6: 4}[e["kind"]] for e in s.table)
+    lu = 2 * nn ** 3 / 3
+    fixed = 2 * np_ * (nx + nu) + 2 * nq * np_ + (np_ + 2 * nn * np_ + 2 * nn * nn + nn) + \
+        2 * nnz * np_ + 2 * (ny + nx) * (nx + nu + nn)
+    per_eval = 2 * nq * nn + 2 * nnz * nn + nn + lu + 2 * nn * nn + 2 * nn
+    return fixed + per_eval * iters_per_sample
+
+
+def _cpu_worker(args):
+    fixture, rows, T = args
+    from acme_jl_amd.model import DiscreteModel
+    from oracle.refpy import RefRunner
+    m = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"))
+    t0 = time.perf_counter()
+    iters = 0
+    for u in rows:
+        r = RefRunner(m)
+        r.run(u)
+        iters += r.report.iters_total
+    return time.perf_counter() - t0, iters
+
+
+def cpu_baseline(fixture, model, pots, amp, T_cpu, budget_s=20.0):
+    """Time the CPU oracle on a bounded, evenly spread sample of the same workload, one
+    instance stream per host core (the reference's DiscreteModel is single-threaded and
+    non-re-entrant, so per-core streams is how it would be scaled)."""
+    import multiprocessing as mp
+    from oracle import refpy
+    refpy.lib()  # build once before forking
+    cores = os.cpu_count() or 1
+    n = len(pots) if pots is not None else len(amp)
+    pick = np.linspace(0, n - 1, cores).astype(int)
+    sig = np.sin(2 * np.pi * 1000.0 / FS * np.arange(T_cpu))
+    jobs = []
+    for i in pick:
+        u = np.zeros((model.nu, T_cpu))
+        u[0] = (amp if np.isscalar(amp) else amp[i]) * sig
+        if pots is not None:
+            u[1:] = pots[i][:, None]
+        jobs.append((fixture, [u], T_cpu))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    units = len(jobs) * T_cpu
+    return {
+        "value": units / wall, "unit": "circuit-instance*samples/sec", "cores": cores,
+        "kind": "port",
+        "sample": f"{len(jobs)} instances spread over the sweep x {T_cpu} samples, one oracle "
+                  f"stream per core, wall {wall:.1f} s (C restatement oracle/acme_ref.c, -O2)",
+        "iters_per_sample": sum(r[1] for r in res) / units,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="superover_grid",
+                    choices=["superover_grid", "diodeclipper_sweep"])
+    ap.add_argument("--instances", type=int, default=None, help="instances per GPU")
+    ap.add_argument("--samples", type=int, default=FS, help="samples per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from acme_jl_amd.dist import broadcast_model
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+
+    n_per_gpu = args.instances or (8192 if args.workload == "superover_grid" else 4096)
+    T = args.samples
+    fixture, pots, amp = grid_inputs(args.workload, rank, world, n_per_gpu, T)
+    # rank 0 owns the model block; everyone else receives it over RCCL (xGMI)
+    model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json")) \
+        if rank == 0 else None
+    model = broadcast_model(model, src=0, device=dev) if world > 1 else model
+
+    runner = ModelRunner(model, n_per_gpu, device=local_rank)
+    u = make_u(torch, dev, model, pots, amp, n_per_gpu, T)
+    y = torch.empty((n_per_gpu, T, model.ny), dtype=torch.float64, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.run_torch(u, y)
+    sync()
+    runner.reset_report()
+    runner.kernel_time(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.run_torch(u, y)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # average launch duration over the timed region: HIP events recorded by the library on
+    # the launch stream around every kernel
+    ms_total, launches = runner.kernel_time()
+    last_ms = ms_total / max(launches, 1)
+    ra = runner.report_arrays()
+    stats = torch.tensor([elapsed, float(ra["iters_total"].sum()), float(ra["n_warn"].sum()),
+                          float((ra["first_nonfinite"] >= 0).sum()), float(ra["iters_max"].max()),
+                          last_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        iters_total, n_warn, n_dead = float(sm[1]), float(sm[2]), float(sm[3])
+        iters_max, last_ms = float(mx[4]), float(mx[5])
+    else:
+        iters_total, n_warn, n_dead, iters_max = (float(stats[1]), float(stats[2]), float(stats[3]),
+                                                  float(stats[4]))
+    checksum = float(torch.nan_to_num(y).abs().sum())
+
+    if rank == 0:
+        units = world * n_per_gpu * T * args.steps
+        value = units / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        iters_per_sample = iters_total / units
+        abytes = algorithmic_bytes(model, n_per_gpu, T)
+        achieved = abytes / (last_ms * 1e-3) / 1e9
+        out = {
+            "metric": "circuit-instance*samples/sec (superover, 44.1 kHz)"
+            if args.workload == "superover_grid" else "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)",
+            "value": value, "unit": "circuit-instance*samples/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": ("examples/superover.jl (pots as inputs: nn=13,nq=29,np=11,nx=11,nu=4), "
+                             f"{n_per_gpu}-instance drive x tone x level grid per GPU "
+                             f"(drive=i/{n_per_gpu * world // 256}, tone,level=linspace(0,1,16)), "
+                             "1 kHz unit sine")
+                if args.workload == "superover_grid" else
+                f"examples/diodeclipper.jl, {n_per_gpu}-instance amplitude sweep 10mV..10V per GPU",
+                "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": FS,
+                "solver": model.solver, "parallelism": f"instance-sharded x{world}",
+                "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,
+                "n_warn": n_warn, "n_nonfinite_instances": n_dead, "y_abs_sum_rank0": checksum,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "acme_run_kernel<Shape<%d,%d,%d,%d,%d,%d>>" % runner.kernel_shape(),
+                "kernel_ms": last_ms, "algorithmic_bytes_per_launch": abytes,
+                "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY 8d); fp64 figure below",
+                "fp64_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
+                / (last_ms * 1e-3) / 1e12 if model.subs else None,
+                "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+            },
+        }
+        if out["roofline"]["fp64_tflops"] is not None:
+            out["roofline"]["fp64_frac"] = out["roofline"]["fp64_tflops"] / FP64_PEAK_TFLOPS
+        if world == 1 and not args.no_cpu_baseline:
+            T_cpu = args.cpu_samples or min(T, 11025)
+            out["cpu_baseline"] = cpu_baseline(fixture, model, pots, amp, T_cpu)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,9 @@ int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int m
 /* milliseconds the last acme_batch_run kernel took on the device (HIP events recorded on
  * the launch stream); synchronises with that launch */
 int acme_batch_last_kernel_ms(acme_batch *b, float *ms);
+/* accumulated device time and count of all launches since the last reset (HIP events on
+ * the launch stream around every kernel); synchronises with the pending launches */
+int acme_batch_kernel_time(acme_batch *b, double *ms_total, long long *launches, int reset);
 
 /* per-instance reports, reports[n_instances]; synchronises */
 int acme_batch_get_report(acme_batch *b, acme_report *reports);
