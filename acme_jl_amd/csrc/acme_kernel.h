@@ -48,9 +48,12 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_> struct Shape {
     static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY;
     static constexpr int SCRATCH = (QBUF + UBUF + YBUF + 1) & ~1;
     static constexpr int STATE = NX + NP + NN;  // doubles of persistent state per instance
+    // per-wave store of the extrapolation origin's LU factors and Jp (one 64-lane slab per
+    // matrix column: lane r keeps row r, conflict-free ds_read/write_b64)
+    static constexpr int ORIGIN = (NN + NP) * 64;
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
         return (per_instance ? INST_PER_BLOCK : 1) * L.total + ROWC * GROUP + ROWI * GROUP +
-               INST_PER_BLOCK * SCRATCH;
+               INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
 };
 
@@ -99,7 +102,7 @@ template <int NN> struct RowLU {
                 orig = wv::shfl16(orig, src);
             }
             double piv = wv::bcast16<k>(a[k]);
-            double inv = 1.0 / piv;
+            double inv = wv::recip(piv);
             double l = a[k] * inv;
             a[k] = (lig == k) ? inv : ((lig > k) ? l : a[k]);
             double lm = (lig > k) ? l : 0.0;
@@ -111,20 +114,22 @@ template <int NN> struct RowLU {
         return ok;
     }
 
-    // solve!: b is distributed one element per lane; returns x likewise
-    static ACME_DEV double solve(const double (&a)[NN > 0 ? NN : 1], int orig, double b, int lig) {
+    // solve!: b is distributed one element per lane; returns x likewise.  `a(jc)` yields
+    // element (lig, j) of the factors (registers for the current J, LDS for the origin's).
+    template <class Acc> static ACME_DEV double solve(Acc &&a, int orig, double b, int lig) {
         double t = wv::shfl16(b, orig);           // all row interchanges at once
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {                // unit lower triangle
             constexpr int j = decltype(jc)::value;
             double xj = wv::bcast16<j>(t);
-            double lm = (lig > j) ? a[j] : 0.0;
+            double lm = (lig > j) ? a(jc) : 0.0;
             t = fma(-lm, xj, t);
         });
         sfor_down<NN>([&](auto jc) ACME_LAMBDA {              // upper triangle, reciprocal diagonal
             constexpr int j = decltype(jc)::value;
-            t = (lig == j) ? a[j] * t : t;
+            double aj = a(jc);
+            t = (lig == j) ? aj * t : t;
             double xj = wv::bcast16<j>(t);
-            double um = (lig < j) ? a[j] : 0.0;
+            double um = (lig < j) ? aj : 0.0;
             t = fma(-um, xj, t);
         });
         return t;
@@ -327,6 +332,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;
     int *lds_rowi = (int *)(lds_rowc + ROWC * GROUP);
     double *lds_scr = lds_rowc + ROWC * GROUP + ROWI * GROUP;
+    double *olu = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + lane;  // [j * 64]
+    double *ojp = olu + NN * 64;                                                     // [j * 64]
     {   // cooperative load of the model image(s) and the row tables
         const int nthreads = WAVES_PER_BLOCK * 64;
         if (!per_inst) {
@@ -368,9 +375,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double x[NXSr];      // state vector, element s*16+lig
     double lp = 0.0;     // extrapolation origin: last_p[lig]
     double lz = 0.0;     //                       last_z[lig]
-    double lu[NNr];      // last_linsolver factors, row lig
-    int lorig = lig;     //   and its row permutation
-    double ljp[NPr];     // last_Jp, row lig
+    int lorig = lig;     // row permutation of last_linsolver (its factors, row lig, and
+                         // last_Jp, row lig, live in LDS: olu[j*64], ojp[j*64])
     double z = 0.0;      // current iterate z[lig]
     double pfull[NQSr];  // q0 + pexp*p, rows s*16+lig
     // per-row results of the latest evaluate!
@@ -472,11 +478,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         set_p(lp);
         evaluate(lz);
         LU::factor(a, orig, lig, grp);
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA { lu[decltype(jc)::value] = a[decltype(jc)::value]; });
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * 64] = a[decltype(jc)::value]; });
         lorig = orig;
-        calc_jp(ljp);
+        double jp0[NPr];
+        calc_jp(jp0);
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * 64] = jp0[decltype(jc)::value]; });
         z = lz;
-        ACME_DBG("origin lane %d kind %d qoff %d res %.17g tv %g %g tc %d %d lu %.17g %.17g lorig %d ljp %.17g pfull %g", lane, rd.kind, rd.qoff, res, tv[0], tv[1], tc[0], tc[1], lu[0], lu[NN > 1 ? 1 : 0], lorig, ljp[0], pfull[0]);
     }
 
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
@@ -488,9 +495,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         double t = 0.0;
         sfor<0, NP>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
-            t = fma(ljp[j], wv::bcast16<j>(dp), t);
+            t = fma(ojp[j * 64], wv::bcast16<j>(dp), t);
         });
-        t = LU::solve(lu, lorig, t, lig);
+        t = LU::solve([&](auto jc) ACME_LAMBDA { return olu[decltype(jc)::value * 64]; }, lorig, t, lig);
         z = sel(need, lz - t, z);
         bool act = need, conv = false;
         its = 0;
@@ -508,20 +515,16 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             if (wv::ballot(stop_conv)) {  // refresh the extrapolation origin (:231-234)
                 double jp[NPr];
                 calc_jp(jp);
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    lu[j] = sel(stop_conv, a[j], lu[j]);
-                });
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    ljp[j] = sel(stop_conv, jp[j], ljp[j]);
-                });
+                if (stop_conv) {  // per-lane predicated LDS stores, no cross-lane ops inside
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * 64] = a[decltype(jc)::value]; });
+                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * 64] = jp[decltype(jc)::value]; });
+                }
                 lorig = sel(stop_conv, orig, lorig);
                 lz = sel(stop_conv, z, lz);
                 lp = sel(stop_conv, target, lp);
             }
             bool step = act && !stop_bad && !stop_conv;
-            double dz = LU::solve(a, orig, res, lig);
+            double dz = LU::solve([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, orig, res, lig);
             z = sel(step, z - dz, z);
             act = step && (its < A.maxiter);
         }

@@ -25,6 +25,11 @@ struct HostSub {
     std::vector<double> pexp, dq, eq, fqprev, fq, q0, init_z;
     std::vector<int> kind, qoff, roff;
     std::vector<double> par;  // n_elems x MAX_ELEM_PAR
+    // performance hint: row_order[pos] = residual row evaluated by lane `pos` (empty = natural
+    // order).  Pre-ordering the equations in the usual pivot order makes the partially
+    // pivoted LU (src/solvers.jl:58-78) find its pivot in place almost always, i.e. without
+    // the cross-lane row interchange; pivots and arithmetic are unchanged.
+    std::vector<int> row_order;
 };
 
 struct HostModel {
@@ -139,8 +144,20 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         put(P.image, L.fq, S.nq, s->fq, d.nq, d.nn);
         put(P.image, L.q0, S.nq, s->q0, d.nq, 1);
         for (int i = 0; i < d.nn; ++i) P.init_state[S.nx + S.np + i] = s->init_z[i];
-        auto RC = [&](int row, int c) -> double & { return P.rowc[(size_t)c * GROUP + row]; };
-        auto RI = [&](int row, int w) -> int & { return P.rowi[(size_t)w * GROUP + row]; };
+        std::vector<int> pos_of(d.nn);
+        for (int i = 0; i < d.nn; ++i) pos_of[i] = i;
+        if (!s->row_order.empty()) {
+            if ((int)s->row_order.size() != d.nn) { err = "row_order has the wrong length"; return false; }
+            std::vector<int> seen(d.nn, 0);
+            for (int pos = 0; pos < d.nn; ++pos) {
+                int r = s->row_order[pos];
+                if (r < 0 || r >= d.nn || seen[r]) { err = "row_order is not a permutation"; return false; }
+                seen[r] = 1;
+                pos_of[r] = pos;
+            }
+        }
+        auto RC = [&](int row, int c) -> double & { return P.rowc[(size_t)c * GROUP + pos_of[row]]; };
+        auto RI = [&](int row, int w) -> int & { return P.rowi[(size_t)w * GROUP + pos_of[row]]; };
         for (size_t e = 0; e < s->kind.size(); ++e) {
             int kind = s->kind[e], knq, knn;
             kind_shape(kind, knq, knn);

@@ -18,20 +18,23 @@ ACME_DEV void block_sync() { __syncthreads(); }
 ACME_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                              __builtin_amdgcn_wave_barrier(); }
 
-template <int CTRL> ACME_DEV int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+// DPP moves with an undefined `old` operand: every lane of a row has a valid source for
+// row_newbcast / row_ror, so no destination pre-initialisation (no extra v_mov) is needed.
+template <int CTRL> ACME_DEV int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false); }
+// value of lane K of each 16-lane row, in every lane of that row.  row_newbcast is the one
+// DPP control gfx950 accepts on 64-bit moves: ONE v_mov_b64_dpp per broadcast double.
+template <int K> ACME_DEV double bcast16(double v) {
+    long long x = __double_as_longlong(v);
+    x = __builtin_amdgcn_mov_dpp(x, 0x150 + K, 0xF, 0xF, false);
+    return __longlong_as_double(x);
 }
-template <int CTRL> ACME_DEV double dpp_d(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = dpp_i<CTRL>(lo);
-    hi = dpp_i<CTRL>(hi);
+template <int K> ACME_DEV int bcast16(int v) { return dpp_i<0x150 + K>(v); }
+// rotate right by R within each 16-lane row (row_ror:R; 32-bit halves, not legal on b64)
+template <int R> ACME_DEV double ror16(double v) {
+    int lo = dpp_i<0x120 + R>(__double2loint(v));
+    int hi = dpp_i<0x120 + R>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-// value of lane K of each 16-lane row, in every lane of that row (row_newbcast:K)
-template <int K> ACME_DEV double bcast16(double v) { return dpp_d<0x150 + K>(v); }
-template <int K> ACME_DEV int bcast16(int v) { return dpp_i<0x150 + K>(v); }
-// rotate right by R within each 16-lane row (row_ror:R)
-template <int R> ACME_DEV double ror16(double v) { return dpp_d<0x120 + R>(v); }
 
 // max over the 16 lanes of each row, result in every lane (4 rotate+max steps)
 ACME_DEV double allmax16(double v) {
@@ -56,6 +59,18 @@ ACME_DEV double shfl16(double v, int src) {
 }
 
 ACME_DEV unsigned long long ballot(bool p) { return __ballot(p); }
+// 1/x: v_rcp_f64 seed + three fused Newton steps (correctly rounded except in rare halfway
+// cases; no div_scale/div_fmas/div_fixup chain -- pivots are never denormal in practice)
+ACME_DEV double recip(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
 ACME_DEV int ffs32(int v) { return __ffs(v); }
 
 }  // namespace wv

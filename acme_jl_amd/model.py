@@ -36,7 +36,8 @@ def _f(m, r, c):
 class SubProblem:
     """One nonlinear sub-problem: matrices of src/ACME.jl:123-128 + element table."""
 
-    def __init__(self, nn, nq, np_, pexp, dq, eq, fqprev, fq, q0, init_z, table):
+    def __init__(self, nn, nq, np_, pexp, dq, eq, fqprev, fq, q0, init_z, table, row_order=None):
+        self.row_order = list(row_order) if row_order else None  # GPU lane assignment hint
         self.nn, self.nq, self.np = nn, nq, np_
         self.pexp, self.dq, self.eq, self.fqprev, self.fq = pexp, dq, eq, fqprev, fq
         self.q0 = np.asarray(q0, dtype=np.float64).reshape(nq)
@@ -87,7 +88,8 @@ class DiscreteModel:
             self.subs.append(SubProblem(
                 nn, nq, np_, _f(d["pexps"][k], nq, np_), _f(d["dqs"][k], np_, nx),
                 _f(d["eqs"][k], np_, nu), _f(d["fqprevs"][k], np_, nnt), _f(d["fqs"][k], nq, nn),
-                d["q0s"][k], d["init_zs"][k], d["tables"][k]))
+                d["q0s"][k], d["init_zs"][k], d["tables"][k],
+                (d.get("row_orders") or [None] * d["nsub"])[k]))
         # mutable state (src/ACME.jl:137,145): starts at zero
         self.x = np.zeros(nx)
 
@@ -109,7 +111,52 @@ class DiscreteModel:
             pexps=[m(s.pexp) for s in self.subs], dqs=[m(s.dq) for s in self.subs],
             eqs=[m(s.eq) for s in self.subs], fqprevs=[m(s.fqprev) for s in self.subs],
             fqs=[m(s.fq) for s in self.subs], q0s=[m(s.q0) for s in self.subs],
-            init_zs=[m(s.init_z) for s in self.subs], tables=[s.table for s in self.subs])
+            init_zs=[m(s.init_z) for s in self.subs], tables=[s.table for s in self.subs],
+            row_orders=[s.row_order for s in self.subs])
+
+    def tune_row_order(self, u=None, T=256, fs=44100):
+        """Performance hint for the GPU kernel (no effect on results): find each sub-problem's
+        usual LU pivot order with a short host-side pilot solve and store it as ``row_order``.
+        ``u``: optional (nu, T) pilot input; default 1 kHz unit sine on input 1, every other
+        input held at 0.5."""
+        from . import hostsolve as hs
+        import collections
+        if not self.subs:
+            return self
+        if u is None:
+            u = np.full((self.nu, T), 0.5)
+            if self.nu:
+                u[0] = np.sin(2 * np.pi * 1000.0 / fs * np.arange(T))
+        if len(self.subs) != 1:
+            return self
+        s = self.subs[0]
+        nleq = hs.HostNleq(s.table, s.fq.tolist(), s.q0.tolist(), s.pexp.tolist())
+        seqs = collections.Counter()
+        plain = hs.lu_factor
+
+        def spy(A):
+            r = plain(A)
+            if r is not None:
+                perm = list(range(len(A)))
+                for k, kp in enumerate(r[1]):
+                    perm[k], perm[kp] = perm[kp], perm[k]
+                seqs[tuple(perm)] += 1
+            return r
+        hs.lu_factor = spy
+        try:
+            solver = hs.HostHomotopySolver(nleq, [0.0] * s.np, s.init_z.tolist())
+            x = np.zeros(self.nx)
+            for n in range(u.shape[1]):
+                p = s.dq @ x + s.eq @ u[:, n]
+                z = np.array(solver.solve(p.tolist()))
+                if not np.isfinite(z).all():
+                    break
+                x = self.x0 + self.a @ x + self.b @ u[:, n] + self.c @ z
+        finally:
+            hs.lu_factor = plain
+        if seqs:
+            s.row_order = list(seqs.most_common(1)[0][0])
+        return self
 
     @classmethod
     def from_dict(cls, d, solver=None):

@@ -50,17 +50,42 @@ class Report(C.Structure):
 # every symbol include/acme_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "acme_last_error", "acme_device_count", "acme_default_options", "acme_model_create",
-    "acme_model_add_subproblem", "acme_model_destroy", "acme_model_kernel_shape",
+    "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
+    "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
     "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  If libacme_hip.so pulled in the
+    system ROCm runtime first, torch would later be bound to that second, mismatching runtime
+    ("No HIP GPUs are available").  Loading torch's copy first -- without importing torch --
+    makes both share one HIP runtime regardless of import order.  Without torch installed
+    (e.g. the Julia ccall route) the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            return None
+    return None
+
+
 class Library:
     """ctypes binding of one shared library implementing include/acme_hip.h."""
 
     def __init__(self, path=DEFAULT_LIBRARY):
+        if os.path.abspath(path) == os.path.abspath(DEFAULT_LIBRARY):
+            self._hip_rt = _preload_torch_hip_runtime()
         if not os.path.exists(path):
             raise AcmeError(
                 f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
@@ -74,6 +99,7 @@ class Library:
         L.acme_model_create.argtypes = [C.c_int] * 4 + [dp] * 8 + [C.POINTER(vp)]
         L.acme_model_add_subproblem.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [dp] * 7 + \
             [C.c_int, ip, ip, ip, dp]
+        L.acme_model_set_row_order.argtypes = [vp, C.c_int, ip, C.c_int]
         L.acme_model_destroy.argtypes = [vp]
         L.acme_model_destroy.restype = None
         L.acme_model_kernel_shape.argtypes = [vp, ip]
@@ -132,7 +158,7 @@ class _ModelHandle:
         lib.check(lib.L.acme_model_create(model.nx, model.nu, model.ny, model.nn_total,
                                           *[_dp(k) for k in keep], C.byref(h)))
         self.h = h
-        for s in model.subs:
+        for k, s in enumerate(model.subs):
             kind, qoff, roff, par = s.elem_arrays()
             mats = [_fa(s.pexp), _fa(s.dq), _fa(s.eq), _fa(s.fqprev), _fa(s.fq), _fa(s.q0),
                     _fa(s.init_z)]
@@ -140,6 +166,9 @@ class _ModelHandle:
             lib.check(lib.L.acme_model_add_subproblem(
                 h, s.nn, s.nq, s.np, *[_dp(k) for k in mats], len(s.table), _ip(kind),
                 _ip(qoff), _ip(roff), _dp(par)))
+            if s.row_order is not None:
+                ro = np.ascontiguousarray(s.row_order, dtype=np.int32)
+                lib.check(lib.L.acme_model_set_row_order(h, k, _ip(ro), len(ro)))
 
     def kernel_shape(self):
         dims = (C.c_int * 6)()

@@ -193,4 +193,5 @@ ACME_DEV double shfl16(double v, int src) {
 }
 ACME_DEV unsigned long long ballot(bool p) { return emu::ballot_bits(p, 500); }
 ACME_DEV int ffs32(int v) { return __builtin_ffs(v); }
+ACME_DEV double recip(double d) { return 1.0 / d; }
 }  // namespace wv

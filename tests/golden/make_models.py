@@ -29,6 +29,6 @@ MODELS = {
 
 if __name__ == "__main__":
     for name, make in MODELS.items():
-        m = make()
+        m = make().tune_row_order()
         m.save(os.path.join(HERE, name + ".json"))
         print(name, "nx", m.nx, "nu", m.nu, "ny", m.ny, [(s.nn, s.nq, s.np) for s in m.subs])
