@@ -36,6 +36,7 @@ enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1 };
 
 struct Dims {
     int nn, nq, np, nx, nu, ny;
+    int rare;  // shape compiled with / model needs the MOSFET, tanh op-amp, JA kinds
 };
 
 // offsets (in doubles) of each matrix inside a model image
@@ -90,6 +91,7 @@ struct KArgs {
     int nterms;              // max non-zeros per Jq row (2..4)
     int has_bjt;             // any BJT row -> second exp needed
     int rare_kinds;          // any MOSFET/MACAK/JA row
+    int prof[4];             // only read by ACME_PROFILE_PIECES builds (tools/profile_pieces.py)
 };
 
 }  // namespace acme

@@ -5,6 +5,8 @@
 // without a usable HIP device every compute entry point fails with ACME_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -41,11 +43,11 @@ template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t
 
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
-#define ACME_X(nn, nq, np, nx, nu, ny)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny>>, \
-                Shape<nn, nq, np, nx, nu, ny>::lds_doubles(false),                                   \
-                Shape<nn, nq, np, nx, nu, ny>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny>::STATE,  \
-                &launch_shape<Shape<nn, nq, np, nx, nu, ny>>},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare)                                                              \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare>>, \
+                Shape<nn, nq, np, nx, nu, ny, rare>::lds_doubles(false),                                   \
+                Shape<nn, nq, np, nx, nu, ny, rare>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare>::STATE,  \
+                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare>>},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -54,7 +56,7 @@ static const std::vector<KernelEntry> &kernel_table() {
 
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
-        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny)
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare)
             return &k;
     return nullptr;
 }

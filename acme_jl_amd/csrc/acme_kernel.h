@@ -37,8 +37,10 @@
 
 namespace acme {
 
-template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_> struct Shape {
+template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0> struct Shape {
     static constexpr int NN = NN_, NQ = NQ_, NP = NP_, NX = NX_, NU = NU_, NY = NY_;
+    // RARE: the MOSFET / tanh op-amp / Jiles-Atherton element functions are compiled in
+    static constexpr bool RARE = RARE_ != 0;
     static constexpr int NQS = (NQ + GROUP - 1) / GROUP;  // q rows per lane
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
@@ -72,6 +74,15 @@ template <int I, class F> ACME_DEV void sfor_down(F &&f) {  // I-1 ... 0
     }
 }
 
+// compile-time lane predicates on the lane-in-group index (same pattern in all 4 rows)
+constexpr unsigned long long rows4(unsigned long long row16) { return (row16 & 0xFFFFull) * 0x0001000100010001ull; }
+template <int K> ACME_DEV bool lig_gt() { return wv::lanes(rows4(0xFFFFull << (K + 1))); }        // lig > K
+template <int K> ACME_DEV bool lig_eq() { return wv::lanes(rows4(1ull << K)); }                   // lig == K
+template <int K> ACME_DEV bool lig_lt() { return wv::lanes(rows4((1ull << K) - 1ull)); }          // lig < K
+template <int K, int N> ACME_DEV bool lig_in() {                                                 // K <= lig < N
+    return wv::lanes(rows4(((1ull << N) - 1ull) & ~((1ull << K) - 1ull)));
+}
+
 ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 
@@ -79,60 +90,111 @@ ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 // LinearSolver, row-per-lane (src/solvers.jl:46-132).  a[j] = element (lig, j).
 // ---------------------------------------------------------------------------------------
 template <int NN> struct RowLU {
+    // Speculative setlhs!: the same elimination WITHOUT looking for a pivot -- valid whenever
+    // the rows already sit in pivot order, which is the normal case because lanes adopt the
+    // pivot order of the previous factorisation (see wave_main).  Branch-free; returns a wave
+    // mask of the lanes that would have been a strictly larger pivot candidate (or saw a zero
+    // pivot): if the calling instance's bits are non-zero the result is discarded and
+    // factor() below redoes the job with full partial pivoting.
+    template <bool AUG>
+    static ACME_DEV unsigned long long factor_inplace(double (&a)[NN > 0 ? NN : 1], double &b) {
+        unsigned long long viol = 0;
+        sfor<0, NN>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = decltype(kc)::value;
+            double piv = wv::bcast16<k>(a[k]);
+            viol |= wv::ballot((lig_in<k + 1, NN>() && fabs(a[k]) > fabs(piv)) || (lig_eq<k>() && piv == 0.0));
+            double inv = wv::recip(piv);
+            double lm = lig_gt<k>() ? a[k] * inv : 0.0;   // multipliers l_ik, 0 on rows <= k
+            a[k] = lig_gt<k>() ? lm : (lig_eq<k>() ? inv : a[k]);
+            // all broadcasts of pivot row k first, then the rank-1 update
+            double bk[NN > 0 ? NN : 1];
+            double bb = 0.0;
+            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                bk[j] = wv::bcast16<k>(a[j]);
+            });
+            if (AUG) bb = wv::bcast16<k>(b);
+            wv::sched_fence();
+            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                a[j] = fma(-lm, bk[j], a[j]);
+            });
+            if (AUG) b = fma(-lm, bb, b);
+        });
+        return viol;
+    }
+
     // setlhs!: in-place LU with partial pivoting (first strict max), reciprocal pivots on
     // the diagonal.  `orig` returns the original row now stored in this lane (the composed
     // row interchanges).  Returns false for an exactly singular matrix.
-    static ACME_DEV bool factor(double (&a)[NN > 0 ? NN : 1], int &orig, int lig, int grp) {
+    // AUG: `b` is carried along as an extra column, i.e. the unit-lower-triangular forward
+    // substitution of solve! (same operations, same order) happens during the elimination.
+    template <bool AUG>
+    static ACME_DEV bool factor(double (&a)[NN > 0 ? NN : 1], int &orig, int lig, int grp, double &b) {
         bool ok = true;
         orig = lig;
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
-            double v = (lig >= k && lig < NN) ? fabs(a[k]) : -1.0;
-            double m = wv::allmax16(v);
-            unsigned long long bal = wv::ballot(v == m);
-            int msk = (int)((bal >> (grp * GROUP)) & 0xFFFFull);
-            int kp = wv::ffs32(msk) - 1;          // first row holding the maximum
-            ok = ok && (m > 0.0);
-            if (wv::ballot(kp != k)) {            // some instance of this wave interchanges
-                int src = (lig == k) ? kp : ((lig == kp) ? k : lig);
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    a[j] = wv::shfl16(a[j], src);
-                });
-                orig = wv::shfl16(orig, src);
-            }
+            // fast path: the in-place candidate already is the first maximum unless some
+            // later row is strictly larger (the usual case with a tuned row order).  Its
+            // reciprocal is started speculatively so that the rcp/Newton chain overlaps the
+            // tail of the previous step's rank-1 update instead of waiting behind the test.
             double piv = wv::bcast16<k>(a[k]);
-            double inv = wv::recip(piv);
-            double l = a[k] * inv;
-            a[k] = (lig == k) ? inv : ((lig > k) ? l : a[k]);
-            double lm = (lig > k) ? l : 0.0;
+            double inv = wv::keep(wv::recip(piv));
+            if (wv::ballot(lig_in<k + 1, NN>() && fabs(a[k]) > fabs(piv))) {
+                double v = lig_in<k, NN>() ? fabs(a[k]) : -1.0;
+                double m = wv::allmax16(v);
+                unsigned long long bal = wv::ballot(v == m);
+                int msk = (int)((bal >> (grp * GROUP)) & 0xFFFFull);
+                int kp = wv::ffs32(msk) - 1;      // first row holding the maximum
+                if (wv::ballot(kp != k)) {        // row interchange k <-> kp
+                    int src = lig_eq<k>() ? kp : ((lig == kp) ? k : lig);
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        a[j] = wv::shfl16(a[j], src);
+                    });
+                    orig = wv::shfl16(orig, src);
+                    if (AUG) b = wv::shfl16(b, src);
+                    piv = wv::bcast16<k>(a[k]);
+                    inv = wv::recip(piv);
+                }
+            }
+            ok = ok && (piv != 0.0);
+            double lm = lig_gt<k>() ? a[k] * inv : 0.0;   // multipliers l_ik, 0 on rows <= k
+            a[k] = lig_gt<k>() ? lm : (lig_eq<k>() ? inv : a[k]);
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
                 a[j] = fma(-lm, wv::bcast16<k>(a[j]), a[j]);
             });
+            if (AUG) b = fma(-lm, wv::bcast16<k>(b), b);
         });
         return ok;
     }
 
-    // solve!: b is distributed one element per lane; returns x likewise.  `a(jc)` yields
-    // element (lig, j) of the factors (registers for the current J, LDS for the origin's).
-    template <class Acc> static ACME_DEV double solve(Acc &&a, int orig, double b, int lig) {
-        double t = wv::shfl16(b, orig);           // all row interchanges at once
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA {                // unit lower triangle
-            constexpr int j = decltype(jc)::value;
-            double xj = wv::bcast16<j>(t);
-            double lm = (lig > j) ? a(jc) : 0.0;
-            t = fma(-lm, xj, t);
-        });
-        sfor_down<NN>([&](auto jc) ACME_LAMBDA {              // upper triangle, reciprocal diagonal
+    // upper-triangular half of solve! (reciprocal diagonal), t = L^-1 P b on entry
+    template <class Acc> static ACME_DEV double back(Acc &&a, double t, int lig) {
+        sfor_down<NN>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
             double aj = a(jc);
-            t = (lig == j) ? aj * t : t;
+            t = lig_eq<j>() ? aj * t : t;
             double xj = wv::bcast16<j>(t);
-            double um = (lig < j) ? aj : 0.0;
+            double um = lig_lt<j>() ? aj : 0.0;
             t = fma(-um, xj, t);
         });
         return t;
+    }
+
+    // solve!: b is distributed one element per lane; returns x likewise.  `a(jc)` yields
+    // element (lig, j) of the factors (registers for the current J, LDS for the origin's).
+    template <class Acc> static ACME_DEV double solve(Acc &&a, double b, int lig) {
+        double t = b;   // stored factors carry no interchanges (lanes adopt the pivot order)
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA {                // unit lower triangle
+            constexpr int j = decltype(jc)::value;
+            double xj = wv::bcast16<j>(t);
+            double lm = lig_gt<j>() ? a(jc) : 0.0;
+            t = fma(-lm, xj, t);
+        });
+        return back(a, t, lig);
     }
 };
 
@@ -148,8 +210,9 @@ ACME_DEV double rcv(const RowDesc &rd, int c) { return rd.rc[c * GROUP]; }
 
 // res and up to four Jq non-zeros (value tv[t] in q column tc[t]) of this lane's row.
 // e[0..4] are the element's q entries, exA/exB the hoisted exponentials.
+template <bool RARE>
 ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, double exB,
-                       bool rare, double &res, double (&tv)[4], int (&tc)[4]) {
+                       double &res, double (&tv)[4], int (&tc)[4]) {
     res = 0.0;
     tv[0] = tv[1] = tv[2] = tv[3] = 0.0;
     tc[0] = tc[1] = tc[2] = tc[3] = rd.qoff;
@@ -241,7 +304,7 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, doub
     } else if (kind == RK_PAD) {  // host-side shape padding: res = q, keeps z_pad = 0
         res = e[0];
         tv[0] = 1.0;
-    } else if (rare) {
+    } else if (RARE) {
         if (kind == RK_MOSFET) {  // src/elements.jl:453-479
             double pol = rcv(rd, 0), lam = rcv(rd, 1);
             int nvt = (int)rcv(rd, 2), na = (int)rcv(rd, 7);
@@ -361,13 +424,19 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     for (int i = lig; i < S::SCRATCH; i += GROUP) qbuf[i] = 0.0;
     wv::wave_fence();
 
+    // Which residual row (equation) this lane evaluates.  It starts as the host's row-order
+    // hint and then follows the LU: whenever a factorisation has to interchange rows, the
+    // lanes ADOPT the pivoted order, so the next factorisation finds its pivots in place.
+    int rowid = lig;
     RowDesc rd;
-    rd.kind = (lig < NN) ? lds_rowi[0 * GROUP + lig] : RK_NONE;
-    rd.erow = lds_rowi[1 * GROUP + lig];
-    rd.qoff = lds_rowi[2 * GROUP + lig];
-    rd.flags = lds_rowi[3 * GROUP + lig];
-    rd.rc = lds_rowc + lig;
-    const bool rare = A.rare_kinds != 0;
+    auto load_rowdesc = [&]() ACME_LAMBDA {
+        rd.kind = (lig < NN) ? lds_rowi[0 * GROUP + rowid] : RK_NONE;
+        rd.erow = lds_rowi[1 * GROUP + rowid];
+        rd.qoff = lds_rowi[2 * GROUP + rowid];
+        rd.flags = lds_rowi[3 * GROUP + rowid];
+        rd.rc = lds_rowc + rowid;
+    };
+    load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
     const int nterms = A.nterms;
 
@@ -375,8 +444,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double x[NXSr];      // state vector, element s*16+lig
     double lp = 0.0;     // extrapolation origin: last_p[lig]
     double lz = 0.0;     //                       last_z[lig]
-    int lorig = lig;     // row permutation of last_linsolver (its factors, row lig, and
-                         // last_Jp, row lig, live in LDS: olu[j*64], ojp[j*64])
+    // last_linsolver's factors and last_Jp live in LDS (olu[j*64], ojp[j*64]), stored in
+    // the lane order in force when they were computed (an LU without internal interchanges
+    // in that order, see adopt()).
     double z = 0.0;      // current iterate z[lig]
     double pfull[NQSr];  // q0 + pexp*p, rows s*16+lig
     // per-row results of the latest evaluate!
@@ -444,7 +514,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         if (rd.kind == RK_BJT) argB = e[1] * rcv(rd, 1);
         double exA = exp(argA);
         double exB = has_bjt ? exp(argB) : 1.0;
-        eval_row(rd, e, exA, exB, rare, res, tv, tc);
+        eval_row<S::RARE>(rd, e, exA, exB, res, tv, tc);
         double chk = res * 0.0;
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
@@ -472,14 +542,27 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         });
     };
 
+    // After a pivoted factorisation the lane at position i holds what was row orig[i]: make
+    // that the lane's row from now on (row descriptor and the latest Jq non-zeros move along).
+    auto adopt = [&]() ACME_LAMBDA {
+        rowid = wv::shfl16(rowid, orig);
+        sfor<0, 4>([&](auto tc_) ACME_LAMBDA {
+            constexpr int t = decltype(tc_)::value;
+            tv[t] = wv::shfl16(tv[t], orig);
+            tc[t] = wv::shfl16(tc[t], orig);
+        });
+        load_rowdesc();
+    };
+
     // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196): the factors and Jp
     // at the origin are recomputed from (p, z), so only (p, z) has to persist in HBM.
     if (NN > 0) {
         set_p(lp);
         evaluate(lz);
-        LU::factor(a, orig, lig, grp);
+        double dummy = 0.0;
+        LU::template factor<false>(a, orig, lig, grp, dummy);
+        adopt();
         sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * 64] = a[decltype(jc)::value]; });
-        lorig = orig;
         double jp0[NPr];
         calc_jp(jp0);
         sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * 64] = jp0[decltype(jc)::value]; });
@@ -497,17 +580,43 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             constexpr int j = decltype(jc)::value;
             t = fma(ojp[j * 64], wv::bcast16<j>(dp), t);
         });
-        t = LU::solve([&](auto jc) ACME_LAMBDA { return olu[decltype(jc)::value * 64]; }, lorig, t, lig);
+        t = LU::solve([&](auto jc) ACME_LAMBDA { return olu[decltype(jc)::value * 64]; }, t, lig);
         z = sel(need, lz - t, z);
         bool act = need, conv = false;
         its = 0;
         while (wv::ballot(act)) {
             its = act ? its + 1 : its;
+#ifdef ACME_PROFILE_PIECES
+            for (int r_ = 0; r_ < A.prof[0]; ++r_) (void)evaluate(z);
+#endif
             bool finite = evaluate(z);
-            double rm = wv::allmax16((lig < NN) ? fabs(res) : 0.0);
+            double rm = wv::allmax16(lig_lt<NN>() ? fabs(res) : 0.0);
             ACME_DBG("  it %d lane %d act %d z %.17g res %.17g J0 %.17g finite %d rm %g", its, lane, (int)act, z, res, a[0], (int)finite, rm);
-            bool ok = LU::factor(a, orig, lig, grp);  // LU before the convergence test
+            // LU before the convergence test (:223-226); res rides along as an augmented
+            // column, so `fwd` = L^-1 P res when the factorisation is done.  First try the
+            // branch-free in-place elimination; only if some instance of this wave needed a
+            // different pivot order (~4 % of factorisations) redo with partial pivoting.
+            double fwd = res;
+            bool ok = true;
+            if (LU::template factor_inplace<true>(a, fwd)) {
+                (void)evaluate(z);
+                fwd = res;
+                ok = LU::template factor<true>(a, orig, lig, grp, fwd);
+                adopt();
+            }
             bool small = rm < A.tol;
+#ifdef ACME_PROFILE_PIECES  // repeat single pieces in situ (results unchanged) to time them
+            for (int r_ = 0; r_ < A.prof[1]; ++r_) {
+                double a2[NNr];
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a2[decltype(jc)::value] = a[decltype(jc)::value] + 1.0; });
+                int o2;
+                double f2 = res;
+                ok = LU::template factor<true>(a2, o2, lig, grp, f2) || ok;
+                rm = fmax(rm, f2 * 0.0);
+            }
+            for (int r_ = 0; r_ < A.prof[2]; ++r_)
+                rm = fmax(rm, 0.0 * LU::back([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, fwd + r_, lig));
+#endif
             bool stop_bad = act && (!finite || !ok);
             bool stop_conv = act && finite && ok && small;
             // hasconverged is evaluated on resmaxabs even after a singular-J return
@@ -519,12 +628,11 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * 64] = a[decltype(jc)::value]; });
                     sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * 64] = jp[decltype(jc)::value]; });
                 }
-                lorig = sel(stop_conv, orig, lorig);
                 lz = sel(stop_conv, z, lz);
                 lp = sel(stop_conv, target, lp);
             }
             bool step = act && !stop_bad && !stop_conv;
-            double dz = LU::solve([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, orig, res, lig);
+            double dz = LU::back([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, fwd, lig);
             z = sel(step, z - dz, z);
             act = step && (its < A.maxiter);
         }

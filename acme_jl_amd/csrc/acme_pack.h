@@ -48,7 +48,7 @@ struct Packed {
 
 inline const std::vector<Dims> &shape_list() {
     static const std::vector<Dims> v = {
-#define ACME_X(nn, nq, np, nx, nu, ny) Dims{nn, nq, np, nx, nu, ny},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare) Dims{nn, nq, np, nx, nu, ny, rare},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -73,6 +73,7 @@ inline bool choose_shape(const Dims &d, Dims &out) {
     const auto &list = shape_list();
     long best = -1;
     for (const Dims &s : list) {
+        if (d.rare && !s.rare) continue;
         if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny) {
             out = s;
             return true;
@@ -104,7 +105,11 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     Dims d{};
     d.nx = m.nx; d.nu = m.nu; d.ny = m.ny;
     const HostSub *s = m.subs.empty() ? nullptr : &m.subs[0];
-    if (s) { d.nn = s->nn; d.nq = s->nq; d.np = s->np; }
+    if (s) {
+        d.nn = s->nn; d.nq = s->nq; d.np = s->np;
+        for (int kd : s->kind)
+            if (kd == EK_MOSFET || kd == EK_MACAK || kd == EK_JA) d.rare = 1;
+    }
     if (d.nn > MAX_NN || d.nq > MAX_NQ || d.np > MAX_NP || d.nx > MAX_NX || d.nu > MAX_NU || d.ny > MAX_NY) {
         err = "model dimensions exceed the limits of the 16-lane kernel (nn<=16, nq<=32, np<=16, nx<=32, nu<=8, ny<=16)";
         return false;
@@ -113,7 +118,7 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     if (force_shape) {
         S = *force_shape;
         if (!(d.nn <= S.nn && d.np <= S.np && d.nx <= S.nx && d.nu <= S.nu && d.ny <= S.ny &&
-              d.nq + (S.nn - d.nn) <= S.nq)) {
+              d.nq + (S.nn - d.nn) <= S.nq && (!d.rare || S.rare))) {
             err = "model does not fit the batch's kernel shape";
             return false;
         }

@@ -59,18 +59,26 @@ ACME_DEV double shfl16(double v, int src) {
 }
 
 ACME_DEV unsigned long long ballot(bool p) { return __ballot(p); }
-// 1/x: v_rcp_f64 seed + three fused Newton steps (correctly rounded except in rare halfway
-// cases; no div_scale/div_fmas/div_fixup chain -- pivots are never denormal in practice)
+// per-lane predicate from a wave-uniform 64-bit lane mask (compile-time constants become two
+// s_mov_b32 feeding v_cndmask directly: no v_cmp, no long-lived SGPR pair)
+ACME_DEV bool lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// 1/x: v_rcp_f64 seed (~23 good bits) + two fused Newton steps -> within 1 ulp of the
+// correctly rounded reciprocal the reference's inv() returns; no div_scale/div_fmas/div_fixup
+// chain on the LU's critical path (pivots are never denormal in practice)
 ACME_DEV double recip(double d) {
     double x = __builtin_amdgcn_rcp(d);
     double e = fma(-d, x, 1.0);
     x = fma(x, e, x);
     e = fma(-d, x, 1.0);
     x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
     return x;
 }
 ACME_DEV int ffs32(int v) { return __ffs(v); }
+// scheduling fence: nothing is moved across (used to keep a batch of DPP broadcasts ahead of
+// the FMAs that consume them: a dependent dpp->fma pair costs ~17 cycles, batched ~9)
+ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// optimisation barrier: the value must be materialised here (keeps a speculative computation
+// on the near side of a branch instead of being sunk below it)
+ACME_DEV double keep(double v) { asm volatile("" : "+v"(v)); return v; }
 
 }  // namespace wv

@@ -20,6 +20,8 @@ using namespace acme;
 
 namespace emu {
 BlockCtx *g_blk = nullptr;
+long long g_count_allmax = 0, g_count_shfl = 0, g_count_recip = 0;
+struct CountPrinter { ~CountPrinter() { if (getenv("ACME_EMU_COUNTS")) fprintf(stderr, "emu counts: allmax16 %lld shfl16(double) %lld recip %lld\n", g_count_allmax, g_count_shfl, g_count_recip); } } g_count_printer;
 int g_debug = getenv("ACME_EMU_DEBUG") ? atoi(getenv("ACME_EMU_DEBUG")) : 0;
 
 asm(R"(
@@ -140,10 +142,10 @@ template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t
 
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
-#define ACME_X(nn, nq, np, nx, nu, ny)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny}, nullptr, Shape<nn, nq, np, nx, nu, ny>::lds_doubles(false), \
-                Shape<nn, nq, np, nx, nu, ny>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny>::STATE,  \
-                &launch_shape<Shape<nn, nq, np, nx, nu, ny>>},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare)                                                              \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare}, nullptr, Shape<nn, nq, np, nx, nu, ny, rare>::lds_doubles(false), \
+                Shape<nn, nq, np, nx, nu, ny, rare>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare>::STATE,  \
+                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare>>},
         ACME_EMU_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -152,7 +154,7 @@ static const std::vector<KernelEntry> &kernel_table() {
 
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
-        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny)
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare)
             return &k;
     return nullptr;
 }

@@ -57,6 +57,7 @@ struct BlockCtx {
 
 extern BlockCtx *g_blk;
 extern int g_debug;
+extern long long g_count_allmax, g_count_shfl, g_count_recip;
 extern "C" void acme_emu_switch(void **save_sp, void *load_sp);
 
 [[noreturn]] inline void die(const char *msg) {
@@ -177,6 +178,7 @@ template <int R> ACME_DEV double ror16(double v) {
     return emu::u2d(emu::exchange(emu::d2u(v), (lane & ~15) + ((lane - R) & 15), 300 + R));
 }
 ACME_DEV double allmax16(double v) {
+    if ((tid() & 63) == 0) emu::g_count_allmax++;
     v = fmax(v, ror16<8>(v));
     v = fmax(v, ror16<4>(v));
     v = fmax(v, ror16<2>(v));
@@ -189,9 +191,13 @@ ACME_DEV int shfl16(int v, int src) {
 }
 ACME_DEV double shfl16(double v, int src) {
     int lane = tid() & 63;
+    if (lane == 0) emu::g_count_shfl++;
     return emu::u2d(emu::exchange(emu::d2u(v), (lane & ~15) + (src & 15), 401));
 }
 ACME_DEV unsigned long long ballot(bool p) { return emu::ballot_bits(p, 500); }
 ACME_DEV int ffs32(int v) { return __builtin_ffs(v); }
-ACME_DEV double recip(double d) { return 1.0 / d; }
+ACME_DEV double recip(double d) { if ((tid() & 63) == 0) emu::g_count_recip++; return 1.0 / d; }
+ACME_DEV double keep(double v) { return v; }
+ACME_DEV void sched_fence() {}
+ACME_DEV bool lanes(unsigned long long mask) { return (mask >> (tid() & 63)) & 1ull; }
 }  // namespace wv
