@@ -22,7 +22,7 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr int INST_PER_BLOCK = GROUPS_PER_WAVE * WAVES_PER_BLOCK;
 constexpr int CHUNK = 16;         // samples staged per coalesced u/y transfer
 constexpr int ROWC = 24;          // precomputed constants per residual row
-constexpr int ROWI = 4;           // ints per residual row: kind, erow, qoff, flags
+constexpr int ROWI = 8;           // ints per residual row: kind, erow, flags, tc[0..3], (spare)
 constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8;
 
 // residual-row kinds (element kind of the row's element; same numbering as the element

@@ -41,6 +41,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0> s
     static constexpr int NN = NN_, NQ = NQ_, NP = NP_, NX = NX_, NU = NU_, NY = NY_;
     // RARE: the MOSFET / tanh op-amp / Jiles-Atherton element functions are compiled in
     static constexpr bool RARE = RARE_ != 0;
+    static constexpr int NT = RARE ? 4 : 3;  // max Jq non-zeros of one residual row
     static constexpr int NQS = (NQ + GROUP - 1) / GROUP;  // q rows per lane
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
@@ -202,105 +203,99 @@ template <int NN> struct RowLU {
 // element nonlinearities, one residual row per lane (src/elements.jl)
 // ---------------------------------------------------------------------------------------
 struct RowDesc {
-    int kind, erow, qoff, flags;
-    const double *rc;  // row constants in LDS: rc[c * GROUP]
+    int kind, erow, flags;
+    int tc[4];         // q rows this residual row depends on == columns of its Jq non-zeros
+    double k[8];       // the row constants the common kinds use, cached in registers
+    const double *rc;  // all row constants in LDS: rc[c * GROUP]
 };
 
 ACME_DEV double rcv(const RowDesc &rd, int c) { return rd.rc[c * GROUP]; }
 
-// res and up to four Jq non-zeros (value tv[t] in q column tc[t]) of this lane's row.
-// e[0..4] are the element's q entries, exA/exB the hoisted exponentials.
-template <bool RARE>
-ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, double exB,
-                       double &res, double (&tv)[4], int (&tc)[4]) {
+// Residual and Jq non-zeros of this lane's row.  e[t] is q[tc[t]] (the q entries the row
+// depends on, in the order of its Jq non-zeros), tv[t] the matching derivative; exA/exB are
+// the hoisted exponentials exp(e[0]*k[0]), exp(e[1]*k[1]).
+//   diode (v, i) | bjt row0 (vE, vC, iE), row1 (vE, vC, iC) | pot row0 (v1, i1, pos),
+//   row1 (v2, i2, pos) | mosfet (vgs, vds, id) | tanh op-amp (vi, vo) | JA (q1..q4)
+template <bool RARE, int NT>
+ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, double exB,
+                       double &res, double (&tv)[NT]) {
     res = 0.0;
-    tv[0] = tv[1] = tv[2] = tv[3] = 0.0;
-    tc[0] = tc[1] = tc[2] = tc[3] = rd.qoff;
+    for (int t = 0; t < NT; ++t) tv[t] = 0.0;
     const int kind = rd.kind;
     if (kind == RK_DIODE) {  // src/elements.jl:238-244
-        res = rcv(rd, 1) * (exA - 1.0) - e[1];
-        tv[0] = rcv(rd, 2) * exA;
+        res = rd.k[1] * (exA - 1.0) - e[1];
+        tv[0] = rd.k[2] * exA;
         tv[1] = -1.0;
-        tc[1] = rd.qoff + 1;
     } else if (kind == RK_BJT) {  // src/elements.jl:323-401
-        const int fl = rd.flags;
         double vE = e[0], vC = e[1];
         double expE = exA, expC = exB;
-        double i_f = rcv(rd, 2) * (expE - 1.0);
-        double i_r = rcv(rd, 3) * (expC - 1.0);
-        double di_f1 = rcv(rd, 4) * expE;
-        double di_r2 = rcv(rd, 5) * expC;
+        double i_f = rd.k[2] * (expE - 1.0);
+        double i_r = rd.k[3] * (expC - 1.0);
+        double di_f1 = rd.k[4] * expE;
+        double di_r2 = rd.k[5] * expC;
         double i_cc = i_f - i_r, di_cc1 = di_f1, di_cc2 = -di_r2;
-        if (fl & (RF_EARLY | RF_KNEE)) {
-            if (!(fl & RF_KNEE)) {  // Early effect only (:335-343)
-                double q1i = 1.0 - vE * rcv(rd, 8) - vC * rcv(rd, 9);
-                i_cc = q1i * (i_f - i_r);
-                di_cc1 = rcv(rd, 18) * (i_f - i_r) + q1i * di_f1;
-                di_cc2 = rcv(rd, 19) * (i_f - i_r) - q1i * di_r2;
-            } else if (!(fl & RF_EARLY)) {  // high-level injection only (:344-356)
-                double q2 = i_f * rcv(rd, 10) + i_r * rcv(rd, 11);
-                double qden = 1.0 + sqrt(1.0 + 4.0 * q2);
-                double qfact = 2.0 / qden;
-                i_cc = qfact * (i_f - i_r);
-                double dq21 = di_f1 * rcv(rd, 10), dq22 = di_r2 * rcv(rd, 11);
-                double dqfact1 = -4.0 * dq21 / (qden - 1.0) / (qden * qden);
-                double dqfact2 = -4.0 * dq22 / (qden - 1.0) / (qden * qden);
-                di_cc1 = dqfact1 * (i_f - i_r) + qfact * di_f1;
-                di_cc2 = dqfact2 * (i_f - i_r) - qfact * di_r2;
-            } else {  // both (:357-373)
-                double q1i = 1.0 - vE * rcv(rd, 8) - vC * rcv(rd, 9);
-                double q2 = i_f * rcv(rd, 10) + i_r * rcv(rd, 11);
-                double qden = 1.0 + sqrt(1.0 + 4.0 * q2);
-                double qfact = 2.0 * q1i / qden;
-                i_cc = qfact * (i_f - i_r);
-                double dq21 = di_f1 * rcv(rd, 10), dq22 = di_r2 * rcv(rd, 11);
-                double dqfact1 = (2.0 * rcv(rd, 18) * qden - q1i * 4.0 * dq21 / (qden - 1.0)) / (qden * qden);
-                double dqfact2 = (2.0 * rcv(rd, 19) * qden - q1i * 4.0 * dq22 / (qden - 1.0)) / (qden * qden);
-                di_cc1 = dqfact1 * (i_f - i_r) + qfact * di_f1;
-                di_cc2 = dqfact2 * (i_f - i_r) - qfact * di_r2;
+        double iBE = rd.k[6] * i_f, diBE1 = rd.k[6] * di_f1;
+        double iBC = rd.k[7] * i_r, diBC2 = rd.k[7] * di_r2;
+        if (RARE) {  // Gummel-Poon refinements (Early effect, high-level injection, leakage)
+            const int fl = rd.flags;
+            if (fl & (RF_EARLY | RF_KNEE)) {
+                if (!(fl & RF_KNEE)) {  // Early effect only (:335-343)
+                    double q1i = 1.0 - vE * rcv(rd, 8) - vC * rcv(rd, 9);
+                    i_cc = q1i * (i_f - i_r);
+                    di_cc1 = rcv(rd, 18) * (i_f - i_r) + q1i * di_f1;
+                    di_cc2 = rcv(rd, 19) * (i_f - i_r) - q1i * di_r2;
+                } else if (!(fl & RF_EARLY)) {  // high-level injection only (:344-356)
+                    double q2 = i_f * rcv(rd, 10) + i_r * rcv(rd, 11);
+                    double qden = 1.0 + sqrt(1.0 + 4.0 * q2);
+                    double qfact = 2.0 / qden;
+                    i_cc = qfact * (i_f - i_r);
+                    double dq21 = di_f1 * rcv(rd, 10), dq22 = di_r2 * rcv(rd, 11);
+                    double dqfact1 = -4.0 * dq21 / (qden - 1.0) / (qden * qden);
+                    double dqfact2 = -4.0 * dq22 / (qden - 1.0) / (qden * qden);
+                    di_cc1 = dqfact1 * (i_f - i_r) + qfact * di_f1;
+                    di_cc2 = dqfact2 * (i_f - i_r) - qfact * di_r2;
+                } else {  // both (:357-373)
+                    double q1i = 1.0 - vE * rcv(rd, 8) - vC * rcv(rd, 9);
+                    double q2 = i_f * rcv(rd, 10) + i_r * rcv(rd, 11);
+                    double qden = 1.0 + sqrt(1.0 + 4.0 * q2);
+                    double qfact = 2.0 * q1i / qden;
+                    i_cc = qfact * (i_f - i_r);
+                    double dq21 = di_f1 * rcv(rd, 10), dq22 = di_r2 * rcv(rd, 11);
+                    double dqfact1 = (2.0 * rcv(rd, 18) * qden - q1i * 4.0 * dq21 / (qden - 1.0)) / (qden * qden);
+                    double dqfact2 = (2.0 * rcv(rd, 19) * qden - q1i * 4.0 * dq22 / (qden - 1.0)) / (qden * qden);
+                    di_cc1 = dqfact1 * (i_f - i_r) + qfact * di_f1;
+                    di_cc2 = dqfact2 * (i_f - i_r) - qfact * di_r2;
+                }
+            }
+            if (fl & RF_ILE) {  // :377-385
+                double expEl = (fl & RF_ETAEL) ? exp(vE * rcv(rd, 14)) : expE;
+                iBE += rcv(rd, 12) * (expEl - 1.0);
+                diBE1 += rcv(rd, 16) * expEl;
+            }
+            if (fl & RF_ILC) {  // :388-396
+                double expCl = (fl & RF_ETACL) ? exp(vC * rcv(rd, 15)) : expC;
+                iBC += rcv(rd, 13) * (expCl - 1.0);
+                diBC2 += rcv(rd, 17) * expCl;
             }
         }
-        double iBE = rcv(rd, 6) * i_f, diBE1 = rcv(rd, 6) * di_f1;
-        double iBC = rcv(rd, 7) * i_r, diBC2 = rcv(rd, 7) * di_r2;
-        if (fl & RF_ILE) {  // :377-385
-            double expEl = (fl & RF_ETAEL) ? exp(vE * rcv(rd, 14)) : expE;
-            iBE += rcv(rd, 12) * (expEl - 1.0);
-            diBE1 += rcv(rd, 16) * expEl;
-        }
-        if (fl & RF_ILC) {  // :388-396
-            double expCl = (fl & RF_ETACL) ? exp(vC * rcv(rd, 15)) : expC;
-            iBC += rcv(rd, 13) * (expCl - 1.0);
-            diBC2 += rcv(rd, 17) * expCl;
-        }
-        tc[1] = rd.qoff + 1;
         tv[2] = -1.0;
         if (rd.erow == 0) {
             res = i_cc + iBE - e[2];
             tv[0] = di_cc1 + diBE1;
             tv[1] = di_cc2;
-            tc[2] = rd.qoff + 2;
         } else {
-            res = -i_cc + iBC - e[3];
+            res = -i_cc + iBC - e[2];
             tv[0] = -di_cc1;
             tv[1] = -di_cc2 + diBC2;
-            tc[2] = rd.qoff + 3;
         }
-    } else if (kind == RK_POT) {  // src/elements.jl:25-30
-        double r = rcv(rd, 0);
+    } else if (kind == RK_POT) {  // src/elements.jl:25-30: (v, i, pos) of this half
+        double r = rd.k[0];
+        double w = (rd.erow == 0) ? e[2] : (1.0 - e[2]);
+        double rw = r * w;
+        res = e[0] - rw * e[1];
         tv[0] = 1.0;
-        tc[2] = rd.qoff + 4;
-        if (rd.erow == 0) {
-            res = e[0] - r * e[4] * e[2];
-            tv[1] = -r * e[4];
-            tv[2] = -r * e[2];
-            tc[1] = rd.qoff + 2;
-        } else {
-            res = e[1] - r * (1.0 - e[4]) * e[3];
-            tv[1] = -r * (1.0 - e[4]);
-            tv[2] = -r * e[3];
-            tc[0] = rd.qoff + 1;
-            tc[1] = rd.qoff + 3;
-        }
+        tv[1] = -rw;
+        tv[2] = -r * e[1];
     } else if (kind == RK_PAD) {  // host-side shape padding: res = q, keeps z_pad = 0
         res = e[0];
         tv[0] = 1.0;
@@ -318,8 +313,6 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, doub
             for (int k = nvt - 2; k >= 0; --k) vt_ = vt_ * xg + rcv(rd, 3 + k);
             for (int k = nvt - 3; k >= 0; --k) dvt_ = dvt_ * xg + rcv(rd, 12 + k);
             double lam_ = vds >= 0.0 ? lam : 0.0;
-            tc[1] = rd.qoff + 1;
-            tc[2] = rd.qoff + 2;
             tv[2] = -1.0;
             if (vgs <= vt_) {
                 res = -id;
@@ -341,12 +334,11 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, doub
             res = tanh(vs) * scale - e[1];
             tv[0] = gain / (ch * ch);
             tv[1] = -1.0;
-            tc[1] = rd.qoff + 1;
         } else if (kind == RK_JA) {  // src/elements.jl:107-129
             double Ms = rcv(rd, 0), al = rcv(rd, 2), c = rcv(rd, 3), k = rcv(rd, 4);
             double s = rcv(rd, 5);    // 1e-4 / Ms
             double cMa = rcv(rd, 6);  // c * Ms / a
-            double q1 = e[0], q2 = e[1], q3 = e[2], q4 = e[3];
+            double q1 = e[0], q2 = e[1], q3 = e[2], q4 = e[NT - 1];
             double coth = 1.0 / tanh(q1);
             double aq1 = fabs(q1);
             double Lq = aq1 < 1e-4 ? q1 / 3.0 : coth - 1.0 / q1;
@@ -363,10 +355,7 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, doub
                          cMa * (q3 + al * q4) * Ld2);
             tv[1] = s * -((1.0 - c) * (1.0 - c)) * k * dM * delta / (den * den) * q3;
             tv[2] = s * ((1.0 - c) * dM * d / den + cMa * Ld);
-            tv[3] = s * (rcv(rd, 7) * Ld - 1.0);  // c*Ms/a*alpha
-            tc[1] = rd.qoff + 1;
-            tc[2] = rd.qoff + 2;
-            tc[3] = rd.qoff + 3;
+            tv[NT - 1] = s * (rcv(rd, 7) * Ld - 1.0);  // c*Ms/a*alpha
         }
     }
 }
@@ -376,7 +365,7 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[5], double exA, doub
 // ---------------------------------------------------------------------------------------
 template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
-    constexpr int NQS = S::NQS, NXS = S::NXS;
+    constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT;
     constexpr int NNr = NN > 0 ? NN : 1, NPr = NP > 0 ? NP : 1, NQSr = NQS > 0 ? NQS : 1,
                   NXSr = NXS > 0 ? NXS : 1;
     constexpr Layout L = S::L;
@@ -432,13 +421,13 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     auto load_rowdesc = [&]() ACME_LAMBDA {
         rd.kind = (lig < NN) ? lds_rowi[0 * GROUP + rowid] : RK_NONE;
         rd.erow = lds_rowi[1 * GROUP + rowid];
-        rd.qoff = lds_rowi[2 * GROUP + rowid];
-        rd.flags = lds_rowi[3 * GROUP + rowid];
+        rd.flags = lds_rowi[2 * GROUP + rowid];
+        sfor<0, 4>([&](auto tc_) ACME_LAMBDA { rd.tc[decltype(tc_)::value] = lds_rowi[(3 + decltype(tc_)::value) * GROUP + rowid]; });
         rd.rc = lds_rowc + rowid;
+        sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
     };
     load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
-    const int nterms = A.nterms;
 
     // ---- persistent per-instance state, in registers for the whole launch --------------
     double x[NXSr];      // state vector, element s*16+lig
@@ -448,13 +437,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // the lane order in force when they were computed (an LU without internal interchanges
     // in that order, see adopt()).
     double z = 0.0;      // current iterate z[lig]
-    double pfull[NQSr];  // q0 + pexp*p, rows s*16+lig
+    double pf[NT];       // (q0 + pexp*p) at the q rows rd.tc[] of this lane's residual row
     // per-row results of the latest evaluate!
     double a[NNr];       // J row -> LU row
     int orig = lig;
     double res = 0.0;
-    double tv[4];
-    int tc[4];
+    double tv[NT];
 
     double *st = A.state + (valid ? inst : 0) * S::STATE;
     sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
@@ -466,19 +454,20 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     if (NN > 0) lz = (valid && lig < NN) ? st[NX + NP + lig] : 0.0;
 
     // ---- helpers ------------------------------------------------------------------------
-    // pfull <- q0 + pexp*p   (set_p closure, src/ACME.jl:237-243)
+    // pfull <- q0 + pexp*p   (set_p closure, src/ACME.jl:237-243), only the entries this
+    // lane's row needs
     auto set_p = [&](double p) ACME_LAMBDA {
-        sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
-            constexpr int s = decltype(sc)::value;
-            pfull[s] = M[L.q0 + s * GROUP + lig];
-        });
-        sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            double pj = wv::bcast16<j>(p);
-            sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
-                constexpr int s = decltype(sc)::value;
-                pfull[s] = fma(M[L.pexp + j * NQ + s * GROUP + lig], pj, pfull[s]);
+        double pb[NPr];
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
+        wv::sched_fence();
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+            constexpr int t = decltype(tc_)::value;
+            double acc = M[L.q0 + rd.tc[t]];
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                acc = fma(M[L.pexp + j * NQ + rd.tc[t]], pb[j], acc);
             });
+            pf[t] = acc;
         });
     };
 
@@ -486,42 +475,34 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // (src/ACME.jl:178-188, src/circuit.jl:10-17).  Leaves J row in a[], residual in res,
     // the row's Jq non-zeros in tv/tc.  Returns true if res and J are finite.
     auto evaluate = [&](double zz) ACME_LAMBDA -> bool {
-        double q[NQSr];
-        sfor<0, NQS>([&](auto sc) ACME_LAMBDA { q[decltype(sc)::value] = pfull[decltype(sc)::value]; });
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            double zj = wv::bcast16<j>(zz);
-            sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
-                constexpr int s = decltype(sc)::value;
-                q[s] = fma(M[L.fq + j * NQ + s * GROUP + lig], zj, q[s]);
+        // q[tc[t]] = pfull + fq*z for the (at most NT) q entries this row depends on: every
+        // lane forms its own, so no cross-lane exchange of q is needed
+        double zb[NNr];
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA { zb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(zz); });
+        wv::sched_fence();
+        double e[NT];
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+            constexpr int t = decltype(tc_)::value;
+            double acc = pf[t];
+            sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                acc = fma(M[L.fq + j * NQ + rd.tc[t]], zb[j], acc);
             });
+            e[t] = acc;
         });
-        wv::wave_fence();
-        sfor<0, NQS>([&](auto sc) ACME_LAMBDA {
-            constexpr int s = decltype(sc)::value;
-            qbuf[s * GROUP + lig] = q[s];
-        });
-        wv::wave_fence();
-        double e[5];
-        e[0] = qbuf[rd.qoff];
-        e[1] = qbuf[rd.qoff + 1];
-        e[2] = qbuf[rd.qoff + 2];
-        e[3] = qbuf[rd.qoff + 3];
-        e[4] = qbuf[rd.qoff + 4];
         // hoisted exponentials: diode exp(v/(eta vT)), BJT exp(vE/..), exp(vC/..)
-        double argA = 0.0, argB = 0.0;
-        if (rd.kind == RK_DIODE || rd.kind == RK_BJT) argA = e[0] * rcv(rd, 0);
-        if (rd.kind == RK_BJT) argB = e[1] * rcv(rd, 1);
-        double exA = exp(argA);
-        double exB = has_bjt ? exp(argB) : 1.0;
-        eval_row<S::RARE>(rd, e, exA, exB, res, tv, tc);
+        const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
+        double exA = exp(expo ? e[0] * rd.k[0] : 0.0);
+        double exB = has_bjt ? exp(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0) : 1.0;
+        eval_row<S::RARE, NT>(rd, e, exA, exB, res, tv);
         double chk = res * 0.0;
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * M[L.fq + j * NQ + tc[0]];
-            acc = fma(tv[1], M[L.fq + j * NQ + tc[1]], acc);
-            if (nterms > 2) acc = fma(tv[2], M[L.fq + j * NQ + tc[2]], acc);
-            if (nterms > 3) acc = fma(tv[3], M[L.fq + j * NQ + tc[3]], acc);
+            double acc = tv[0] * M[L.fq + j * NQ + rd.tc[0]];
+            sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                acc = fma(tv[t], M[L.fq + j * NQ + rd.tc[t]], acc);
+            });
             a[j] = acc;
             chk = fma(acc, 0.0, chk);
         });
@@ -531,13 +512,14 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     };
 
     // calc_Jp closure (src/ACME.jl:246-251): Jp row = Jq row * pexp
-    auto calc_jp = [&](double (&jp)[NPr]) {
+    auto calc_jp = [&](double (&jp)[NPr]) ACME_LAMBDA {
         sfor<0, NP>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * M[L.pexp + j * NQ + tc[0]];
-            acc = fma(tv[1], M[L.pexp + j * NQ + tc[1]], acc);
-            if (nterms > 2) acc = fma(tv[2], M[L.pexp + j * NQ + tc[2]], acc);
-            if (nterms > 3) acc = fma(tv[3], M[L.pexp + j * NQ + tc[3]], acc);
+            double acc = tv[0] * M[L.pexp + j * NQ + rd.tc[0]];
+            sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                acc = fma(tv[t], M[L.pexp + j * NQ + rd.tc[t]], acc);
+            });
             jp[j] = acc;
         });
     };
@@ -546,10 +528,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // that the lane's row from now on (row descriptor and the latest Jq non-zeros move along).
     auto adopt = [&]() ACME_LAMBDA {
         rowid = wv::shfl16(rowid, orig);
-        sfor<0, 4>([&](auto tc_) ACME_LAMBDA {
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
             tv[t] = wv::shfl16(tv[t], orig);
-            tc[t] = wv::shfl16(tc[t], orig);
+            pf[t] = wv::shfl16(pf[t], orig);
         });
         load_rowdesc();
     };

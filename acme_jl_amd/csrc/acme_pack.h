@@ -107,8 +107,16 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     const HostSub *s = m.subs.empty() ? nullptr : &m.subs[0];
     if (s) {
         d.nn = s->nn; d.nq = s->nq; d.np = s->np;
-        for (int kd : s->kind)
+        for (size_t e = 0; e < s->kind.size(); ++e) {
+            int kd = s->kind[e];
             if (kd == EK_MOSFET || kd == EK_MACAK || kd == EK_JA) d.rare = 1;
+            if (kd == EK_BJT) {  // any Gummel-Poon refinement (src/elements.jl:331-396)
+                const double *p = &s->par[e * MAX_ELEM_PAR];
+                if (p[6] != 0 || p[7] != 0 || !std::isinf(p[10]) || !std::isinf(p[11]) || !std::isinf(p[12]) ||
+                    !std::isinf(p[13]))
+                    d.rare = 1;
+            }
+        }
     }
     if (d.nn > MAX_NN || d.nq > MAX_NQ || d.np > MAX_NP || d.nx > MAX_NX || d.nu > MAX_NU || d.ny > MAX_NY) {
         err = "model dimensions exceed the limits of the 16-lane kernel (nn<=16, nq<=32, np<=16, nx<=32, nu<=8, ny<=16)";
@@ -172,7 +180,19 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
                 if (row >= d.nn) { err = "element table row out of range"; return false; }
                 RI(row, 0) = kind;  // RowKind numbering == element kind numbering
                 RI(row, 1) = er;
-                RI(row, 2) = s->qoff[e];
+                // q rows the residual row depends on = columns of its Jq non-zeros
+                const int q0_ = s->qoff[e];
+                int tcs[4] = {q0_, q0_, q0_, q0_};
+                switch (kind) {
+                case EK_DIODE: tcs[1] = q0_ + 1; break;                                     // (v, i)
+                case EK_BJT: tcs[1] = q0_ + 1; tcs[2] = q0_ + 2 + er; break;                // (vE, vC, iE|iC)
+                case EK_POT: tcs[0] = q0_ + er; tcs[1] = q0_ + 2 + er; tcs[2] = q0_ + 4; break;  // (v, i, pos)
+                case EK_MOSFET: tcs[1] = q0_ + 1; tcs[2] = q0_ + 2; break;
+                case EK_MACAK: tcs[1] = q0_ + 1; break;
+                case EK_JA: tcs[1] = q0_ + 1; tcs[2] = q0_ + 2; tcs[3] = q0_ + 3; break;
+                default: break;
+                }
+                for (int t = 0; t < 4; ++t) RI(row, 3 + t) = tcs[t];
                 int flags = 0;
                 switch (kind) {
                 case EK_DIODE: {  // src/elements.jl:238-244
@@ -249,7 +269,8 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
                     err = "unknown element kind";
                     return false;
                 }
-                RI(row, 3) = flags;
+                RI(row, 2) = flags;
+                if (kind == EK_BJT && flags) P.rare_kinds = 1;  // Gummel-Poon terms live in the RARE build
             }
         }
     }
@@ -258,7 +279,7 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         int qrow = d.nq + (r - d.nn);
         P.image[L.fq + (size_t)r * S.nq + qrow] = 1.0;
         P.rowi[0 * GROUP + r] = RK_PAD;
-        P.rowi[2 * GROUP + r] = qrow;
+        for (int t = 0; t < 4; ++t) P.rowi[(3 + t) * GROUP + r] = qrow;
     }
     return true;
 }
