@@ -103,10 +103,14 @@ template <int NN> struct RowLU {
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
             double piv = wv::bcast16<k>(a[k]);
-            viol |= wv::ballot((lig_in<k + 1, NN>() && fabs(a[k]) > fabs(piv)) || (lig_eq<k>() && piv == 0.0));
+            // scalar mask arithmetic only: rows k+1..NN-1 with a strictly larger candidate, or
+            // a zero pivot (every lane of the instance sees the same piv)
+            viol |= (wv::ballot(fabs(a[k]) > fabs(piv)) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))) |
+                    wv::ballot(piv == 0.0);
             double inv = wv::recip(piv);
             double lm = lig_gt<k>() ? a[k] * inv : 0.0;   // multipliers l_ik, 0 on rows <= k
-            a[k] = lig_gt<k>() ? lm : (lig_eq<k>() ? inv : a[k]);
+            double dk = lig_eq<k>() ? inv : a[k];          // reciprocal pivot on the diagonal
+            a[k] = lig_gt<k>() ? lm : dk;
             // all broadcasts of pivot row k first, then the rank-1 update
             double bk[NN > 0 ? NN : 1];
             double bb = 0.0;
@@ -453,6 +457,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     if (NP > 0) lp = (valid && lig < NP) ? st[NX + lig] : 0.0;
     if (NN > 0) lz = (valid && lig < NN) ? st[NX + NP + lig] : 0.0;
 
+#ifdef ACME_PROFILE_PIECES
+    double prof_sink = 0.0;
+#endif
     // ---- helpers ------------------------------------------------------------------------
     // pfull <- q0 + pexp*p   (set_p closure, src/ACME.jl:237-243), only the entries this
     // lane's row needs
@@ -569,7 +576,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         while (wv::ballot(act)) {
             its = act ? its + 1 : its;
 #ifdef ACME_PROFILE_PIECES
-            for (int r_ = 0; r_ < A.prof[0]; ++r_) (void)evaluate(z);
+            for (int r_ = 0; r_ < A.prof[0]; ++r_) { (void)evaluate(z + 1e-30 * r_); prof_sink += res + a[0]; }
 #endif
             bool finite = evaluate(z);
             double rm = wv::allmax16(lig_lt<NN>() ? fabs(res) : 0.0);
@@ -590,14 +597,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
 #ifdef ACME_PROFILE_PIECES  // repeat single pieces in situ (results unchanged) to time them
             for (int r_ = 0; r_ < A.prof[1]; ++r_) {
                 double a2[NNr];
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a2[decltype(jc)::value] = a[decltype(jc)::value] + 1.0; });
-                int o2;
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a2[decltype(jc)::value] = a[decltype(jc)::value] + (double)r_; });
                 double f2 = res;
-                ok = LU::template factor<true>(a2, o2, lig, grp, f2) || ok;
-                rm = fmax(rm, f2 * 0.0);
+                prof_sink += (double)(LU::template factor_inplace<true>(a2, f2) & 1ull) + f2 + a2[NN - 1];
             }
             for (int r_ = 0; r_ < A.prof[2]; ++r_)
-                rm = fmax(rm, 0.0 * LU::back([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, fwd + r_, lig));
+                prof_sink += LU::back([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, fwd + r_, lig);
 #endif
             bool stop_bad = act && (!finite || !ok);
             bool stop_conv = act && finite && ok && small;
@@ -810,6 +815,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             rp[RW_FIRST_NONFINITE] = first_nonfinite;
             rp[RW_ITERS_TOTAL] = iters_total;
             rp[RW_ITERS_MAX] = iters_max;
+#ifdef ACME_PROFILE_PIECES
+            if (prof_sink == 1.2345e300) rp[RW_ITERS_MAX] = -1;
+#endif
         }
     }
 }

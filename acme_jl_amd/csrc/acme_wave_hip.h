@@ -58,7 +58,7 @@ ACME_DEV double shfl16(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-ACME_DEV unsigned long long ballot(bool p) { return __ballot(p); }
+ACME_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // per-lane predicate from a wave-uniform 64-bit lane mask (compile-time constants become two
 // s_mov_b32 feeding v_cndmask directly: no v_cmp, no long-lived SGPR pair)
 ACME_DEV bool lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }

@@ -76,3 +76,37 @@ def assert_close(y, yref, rtol=RTOL):
     err = float(np.abs(y - yref).max())
     assert err <= rtol * scale, f"max abs err {err:.3e} > {rtol:g} * {scale:.3g}"
     return err / scale
+
+
+def analytic_cases():
+    """(name, model, u[N,nu,T]) for the reference's small analytic test circuits; they run in
+    the padded generic kernel shapes and cover every element kind."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    one = Fraction(1)
+    cases = []
+    isc, ise, etac, etae, bf, br = 1e-6, 2e-6, 1.1, 1.0, 100, 10
+    for typ in ("npn", "pnp"):
+        m = DiscreteModel(circuits.bjt_test_circuit(typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br), one)
+        cases.append((f"bjt_em_{typ}", m, circuits.bjt_test_input(typ)[None]))
+        m = DiscreteModel(circuits.bjt_test_circuit(
+            typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br, ile=50e-9, ilc=100e-9,
+            etacl=1.2, etael=1.1, vaf=10, var=50, ikf=50e-3, ikr=500e-3), one)
+        cases.append((f"bjt_gp_{typ}", m, circuits.bjt_test_input(typ)[None]))
+    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, bf=bf, br=br, vaf=10, var=50), one)
+    cases.append(("bjt_early_npn", m, circuits.bjt_test_input("npn")[None]))
+    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, bf=bf, br=br, ikf=50e-3, ikr=500e-3), one)
+    cases.append(("bjt_knee_npn", m, circuits.bjt_test_input("npn")[None]))
+    vg, vd = np.meshgrid(np.linspace(0, 5, 10), np.linspace(0, 5, 10))
+    for typ, pol in (("n", 1), ("p", -1)):
+        m = DiscreteModel(circuits.mosfet_test_circuit(typ, vt=(-1.2454, -0.199, -0.0483), alpha=(0.0205, -0.0017), lam=0.05), one)
+        cases.append((f"mosfet_{typ}", m, pol * np.stack([vg.ravel(), vd.ravel()])[None]))
+    m = DiscreteModel(circuits.macak_test_circuit(), Fraction(1 / 44100))
+    cases.append(("macak", m, np.linspace(-1, 1, 300)[None, None, :]))
+    m = DiscreteModel(circuits.ja_inductor_circuit(), Fraction(1, 44100))
+    u = np.concatenate([np.full(400, 0.1), np.full(400, -0.1), np.zeros(100)])
+    cases.append(("ja_inductor", m, np.stack([u, 0.5 * u])[:, None, :]))
+    c, _ = circuits.resistor_diode_circuit()
+    cases.append(("resistor_diode", DiscreteModel(c, one), np.zeros((1, 0, 3))))
+    return cases

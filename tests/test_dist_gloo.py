@@ -1,0 +1,68 @@
+"""World-size-2 tests of the sharding helpers on CPU (gloo): model broadcast, ragged output
+gather, report reduction -- the N>1 path of bench.py without GPUs."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT, load
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from acme_jl_amd.dist import broadcast_model, gather_outputs, reduce_reports, shard_range
+    from helpers import load as _load
+    model = _load("superover_var") if rank == 0 else None
+    model = broadcast_model(model, src=0)
+    ref = _load("superover_var")
+    same = all(np.array_equal(getattr(model, k), getattr(ref, k)) for k in ("a", "b", "c", "dy", "fy")) and \
+        np.array_equal(model.subs[0].fq, ref.subs[0].fq) and model.subs[0].table == ref.subs[0].table and \
+        model.subs[0].row_order == ref.subs[0].row_order
+    n_total = 11                                    # ragged: 6 + 5
+    lo, hi = shard_range(n_total, rank, world)
+    y_local = torch.arange(lo, hi, dtype=torch.float64)[:, None, None].expand(hi - lo, 4, 1).contiguous()
+    counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    y = gather_outputs(y_local, counts, dst=0)
+    rep = dict(n_warn=np.array([rank + 1]), first_nonfinite=np.array([-1 if rank else 3]),
+               iters_total=np.array([10 * (rank + 1)]), iters_max=np.array([7 + rank]))
+    tot = reduce_reports(rep)
+    if rank == 0:
+        ok = same and y.shape == (n_total, 4, 1) and torch.equal(y[:, 0, 0], torch.arange(n_total, dtype=torch.float64))
+        ok = ok and tot == dict(n_warn=3, n_nonfinite=1, iters_total=30, iters_max=8)
+        out.put(bool(ok))
+    else:
+        out.put(bool(same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_gather_reduce():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(res)
+
+
+def test_shard_range_covers_everything():
+    from acme_jl_amd.dist import shard_range
+    for n in (1, 7, 8192, 65536, 16385):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -38,3 +38,82 @@ def test_emulated_state_roundtrip(emu_lib):
     assert np.array_equal(y_once, y_split)
     x, p, z = r.get_state()
     assert x.shape == (3, m.nx) and p.shape == (3, 2) and z.shape == (3, 2)
+
+
+def test_emulated_analytic_circuits(emu_lib):
+    """Every element kind (diode, BJT Ebers-Moll + all Gummel-Poon branches, MOSFET, tanh
+    op-amp, Jiles-Atherton core) through the padded generic shapes."""
+    from helpers import analytic_cases
+    for name, m, u in analytic_cases():
+        r = emu_runner(emu_lib, m, u.shape[0])
+        y = r.run(u)
+        yref, its = oracle_run(m, u)
+        rel = assert_close(y, yref)
+        print(name, r.kernel_shape(), f"rel err {rel:.2e}")
+
+
+def test_emulated_failure_semantics(emu_lib):
+    """test/runtests.jl:170-183: unsolvable input -> warning + finite output; Inf input ->
+    the reference throws; that instance stops, the others are unaffected."""
+    import warnings
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import AcmeError
+    m = DiscreteModel(circuits.no_solution_circuit(), Fraction(1))
+    r = emu_runner(emu_lib, m, 3)
+    u = np.array([[[1.0, 1.0]], [[-1.0, -1.0]], [[1.0, 1.0]]])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = r.run(u)
+    assert any("Failed to converge" in str(x.message) for x in w)
+    ra = r.report_arrays()
+    assert ra["n_warn"].tolist() == [0, 2, 0] and ra["first_nonconverged"].tolist() == [-1, 0, -1]
+    assert np.isfinite(y).all() and y[0, 0, 0] == y[0, 0, 1]
+    np.testing.assert_allclose(y[0, 0, 0], 25e-3 * np.log(1 / 1e-12 + 1), rtol=1e-9)
+    r = emu_runner(emu_lib, m, 2)
+    u = np.array([[[1.0, np.inf, 1.0]], [[1.0, 1.0, 1.0]]])
+    with pytest.raises(AcmeError, match="non-finite"):
+        r.run(u)
+    ra = r.report_arrays()
+    assert ra["first_nonfinite"].tolist() == [1, -1]
+    y = r.run(u, check=False)          # instance 0 stays dead, instance 1 keeps running
+    assert np.isnan(y[0]).all() and np.isfinite(y[1]).all()
+
+
+def test_emulated_per_instance_matrices(emu_lib):
+    """Monte-Carlo style batch: every instance has its own component values."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.circuit import capacitor, resistor
+    from acme_jl_amd.model import DiscreteModel
+    models = []
+    for k in range(5):
+        c = examples.diodeclipper()
+        c.elements["r1"] = resistor(1e3 * (1 + 0.05 * (k - 2)))
+        c.elements["c1"] = capacitor(47e-9 * (1 - 0.03 * (k - 2)))
+        models.append(DiscreteModel(c, Fraction(1, 44100)))
+    u = sweep_inputs("diodeclipper", 5, 150)
+    from acme_jl_amd.runner import ModelRunner
+    r = ModelRunner(models[0], 5, models=models, lib=emu_lib)
+    y = r.run(u)
+    for k in range(5):
+        yref, _ = oracle_run(models[k], u[k:k + 1])
+        assert_close(y[k:k + 1], yref)
+    assert np.abs(y[0] - y[4]).max() > 1e-4   # the instances really differ
+
+
+def test_emulated_tight_tolerance_parity(emu_lib):
+    """With set_resabstol!(1e-13) on both sides stopping-test flips are harmless: the two
+    implementations must agree to rounding level (helpers.RTOL_TIGHT)."""
+    from helpers import RTOL_TIGHT
+    from oracle.refpy import RefRunner
+    m = load("birdie_var")
+    u = sweep_inputs("birdie_var", 6, 300)
+    r = emu_runner(emu_lib, m, 6)
+    r.set_resabstol(1e-13)
+    y = r.run(u)
+    for i in range(6):
+        rr = RefRunner(m)
+        rr.set_resabstol(1e-13)
+        assert_close(y[i:i + 1], rr.run(u[i])[None], rtol=RTOL_TIGHT)

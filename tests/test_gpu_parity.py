@@ -77,3 +77,127 @@ def test_device_pointer_path(hip_lib):
     yref, _ = oracle_run(m, u)
     assert_close(yt.cpu().numpy().transpose(0, 2, 1), yref)
     assert r.last_kernel_ms() > 0
+
+
+def test_analytic_circuits_all_element_kinds(hip_lib):
+    """diode, BJT (Ebers-Moll + every Gummel-Poon branch), MOSFET, tanh op-amp, JA core:
+    the reference's analytic test circuits (test/runtests.jl:431-662) vs the oracle."""
+    from helpers import analytic_cases
+    for name, m, u in analytic_cases():
+        r = runner(hip_lib, m, u.shape[0])
+        y = r.run(u)
+        yref, _ = oracle_run(m, u)
+        rel = assert_close(y, yref)
+        print(name, r.kernel_shape(), f"rel err {rel:.2e}")
+
+
+def test_bjt_ebers_moll_known_answer(hip_lib):
+    """test/runtests.jl:489-510 straight on the GPU path (atol 1e-10)."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    isc, ise, etac, etae, bf, br = 1e-6, 2e-6, 1.1, 1.0, 100, 10
+    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br),
+                      Fraction(1))
+    ve, vc, ie, ic = runner(hip_lib, m, 1).run(circuits.bjt_test_input("npn"))
+    np.testing.assert_allclose(ie, ise * (np.exp(ve / (etae * 25e-3)) - 1)
+                               - br / (1 + br) * isc * (np.exp(vc / (etac * 25e-3)) - 1), atol=1e-10, rtol=0)
+    np.testing.assert_allclose(ic, -bf / (1 + bf) * ise * (np.exp(ve / (etae * 25e-3)) - 1)
+                               + isc * (np.exp(vc / (etac * 25e-3)) - 1), atol=1e-10, rtol=0)
+
+
+def test_failure_semantics(hip_lib):
+    """test/runtests.jl:170-183 on the GPU: warn + finite output; Inf input -> error."""
+    import warnings
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import AcmeError
+    m = DiscreteModel(circuits.no_solution_circuit(), Fraction(1))
+    r = runner(hip_lib, m, 3)
+    u = np.array([[[1.0, 1.0]], [[-1.0, -1.0]], [[1.0, 1.0]]])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = r.run(u)
+    assert any("Failed to converge" in str(x.message) for x in w)
+    ra = r.report_arrays()
+    assert ra["n_warn"].tolist() == [0, 2, 0]
+    assert np.isfinite(y).all() and y[0, 0, 0] == y[0, 0, 1]
+    r = runner(hip_lib, m, 2)
+    u = np.array([[[1.0, np.inf, 1.0]], [[1.0, 1.0, 1.0]]])
+    with pytest.raises(AcmeError, match="non-finite"):
+        r.run(u)
+    assert r.report_arrays()["first_nonfinite"].tolist() == [1, -1]
+
+
+def test_dimension_mismatch(hip_lib):
+    """checkiosizes (src/ACME.jl:625-635)."""
+    from acme_jl_amd.runner import DimensionMismatch
+    r = runner(hip_lib, load("diodeclipper"), 1)
+    with pytest.raises(DimensionMismatch):
+        r.run(np.zeros((2, 10)))
+    with pytest.raises(DimensionMismatch):
+        r.run(np.zeros((1, 10)), y=np.zeros((1, 11)))
+
+
+def test_per_instance_matrices(hip_lib):
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.circuit import capacitor, resistor
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    models = []
+    for k in range(21):
+        c = examples.diodeclipper()
+        c.elements["r1"] = resistor(1e3 * (1 + 0.005 * (k - 10)))
+        c.elements["c1"] = capacitor(47e-9 * (1 - 0.003 * (k - 10)))
+        models.append(DiscreteModel(c, Fraction(1, 44100)))
+    u = sweep_inputs("diodeclipper", 21, 1000)
+    y = ModelRunner(models[0], 21, models=models, lib=hip_lib).run(u)
+    for k in range(21):
+        yref, _ = oracle_run(models[k], u[k:k + 1])
+        assert_close(y[k:k + 1], yref)
+
+
+def test_tight_tolerance_parity(hip_lib):
+    """set_resabstol!(1e-13) on both sides: agreement to rounding level (RTOL_TIGHT)."""
+    from helpers import RTOL_TIGHT
+    from oracle.refpy import RefRunner
+    for name, N, T in (("birdie_var", 8, 1024), ("superover_fixed", 6, 700)):
+        m = load(name)
+        u = sweep_inputs(name, N, T)
+        r = runner(hip_lib, m, N)
+        r.set_resabstol(1e-13)
+        y = r.run(u)
+        for i in range(N):
+            rr = RefRunner(m)
+            rr.set_resabstol(1e-13)
+            assert_close(y[i:i + 1], rr.run(u[i])[None], rtol=RTOL_TIGHT)
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE config 2 scale (4096-instance diode-clipper sweep, 1 s of audio) through
+    size-independent properties: block-split invariance, instance-permutation invariance,
+    odd symmetry breaking bounded by the diode mismatch, and spot parity on 8 instances."""
+    import torch
+    m = load("diodeclipper")
+    N, T = 4096, 44100
+    amp = 10.0 ** (-2 + 3 * np.arange(N) / (N - 1))
+    s = torch.sin(2 * np.pi * 1000 / 44100 * torch.arange(T, dtype=torch.float64, device="cuda"))
+    u = (torch.as_tensor(amp, device="cuda")[:, None] * s[None, :])[:, :, None].contiguous()
+    r1 = runner(hip_lib, m, N)
+    y1 = r1.run_torch(u)
+    r1.check()
+    # the same run in 3 unequal blocks
+    r2 = runner(hip_lib, m, N)
+    y2 = torch.cat([r2.run_torch(u[:, a:b].contiguous()) for a, b in ((0, 1000), (1000, 30001), (30001, T))], dim=1)
+    assert torch.equal(y1, y2)
+    # instances reversed
+    r3 = runner(hip_lib, m, N)
+    y3 = r3.run_torch(torch.flip(u, dims=[0]).contiguous())
+    assert torch.equal(y1, torch.flip(y3, dims=[0]))
+    # the clipper limits the output to a diode drop
+    assert float(y1.abs().max()) < 1.0
+    idx = np.linspace(0, N - 1, 8).astype(int)
+    yref, _ = oracle_run(m, u[idx].cpu().numpy().transpose(0, 2, 1))
+    assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
