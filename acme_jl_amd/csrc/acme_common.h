@@ -40,18 +40,23 @@ struct Dims {
 };
 
 // offsets (in doubles) of each matrix inside a model image
+// pexps/fqs/q0s are stored ROW-GATHERED: for residual row r and its t-th Jq non-zero (q row
+// tc[r][t]) the image holds  fqr[(t*nn + j)*16 + r] = fq[tc[r][t], j]  (likewise pexpr, q0r).
+// The lane that evaluates row r then reads consecutive addresses for fixed (t, j): no
+// indirection and no LDS bank conflicts (the plain fq[tc + j*nq] form was ~39 % conflicts).
 struct Layout {
-    int dq, eq, pexp, fq, q0, a, b, c, x0, dy, ey, fy, y0, total;
+    int dq, eq, pexpr, fqr, q0r, a, b, c, x0, dy, ey, fy, y0, total;
 };
 
-ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int ny) {
+ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int ny, int nt) {
     Layout L{};
     int o = 0;
-    L.dq = o;   o += np * nx;
-    L.eq = o;   o += np * nu;
-    L.pexp = o; o += nq * np;
-    L.fq = o;   o += nq * nn;
-    L.q0 = o;   o += nq;
+    (void)nq;
+    L.dq = o;    o += np * nx;
+    L.eq = o;    o += np * nu;
+    L.pexpr = o; o += nt * np * GROUP;
+    L.fqr = o;   o += nt * nn * GROUP;
+    L.q0r = o;   o += nt * GROUP;
     L.a = o;    o += nx * nx;
     L.b = o;    o += nx * nu;
     L.c = o;    o += nx * nn;

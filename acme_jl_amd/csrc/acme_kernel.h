@@ -45,15 +45,17 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0> s
     static constexpr int NQS = (NQ + GROUP - 1) / GROUP;  // q rows per lane
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
-    static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY);
-    // per-instance LDS scratch (doubles): q exchange | u tile | y tile
-    static constexpr int QBUF = GROUP * (NQS > 0 ? NQS : 1) + 8;
+    static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY, RARE_ != 0 ? 4 : 3);
+    // per-instance LDS scratch (doubles): u tile | y tile
     static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY;
-    static constexpr int SCRATCH = (QBUF + UBUF + YBUF + 1) & ~1;
+    static constexpr int SCRATCH = (UBUF + YBUF + 2) & ~1;
     static constexpr int STATE = NX + NP + NN;  // doubles of persistent state per instance
-    // per-wave store of the extrapolation origin's LU factors and Jp (one 64-lane slab per
-    // matrix column: lane r keeps row r, conflict-free ds_read/write_b64)
-    static constexpr int ORIGIN = (NN + NP) * 64;
+    // per-wave store of the extrapolation origin's LU factors and Jp: one slab per matrix
+    // column holding the NN rows of each of the wave's 4 instances back to back (lane r keeps
+    // row r: consecutive addresses, conflict-free ds_read/write_b64).  LDS per block decides
+    // whether 2 blocks (= 2 waves/SIMD) fit a CU, so the slabs are packed to NN rows, not 16.
+    static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
+    static constexpr int ORIGIN = (NN + NP) * OSTRIDE + GROUP;
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
         return (per_instance ? INST_PER_BLOCK : 1) * L.total + ROWC * GROUP + ROWI * GROUP +
                INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
@@ -208,7 +210,6 @@ template <int NN> struct RowLU {
 // ---------------------------------------------------------------------------------------
 struct RowDesc {
     int kind, erow, flags;
-    int tc[4];         // q rows this residual row depends on == columns of its Jq non-zeros
     double k[8];       // the row constants the common kinds use, cached in registers
     const double *rc;  // all row constants in LDS: rc[c * GROUP]
 };
@@ -388,8 +389,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;
     int *lds_rowi = (int *)(lds_rowc + ROWC * GROUP);
     double *lds_scr = lds_rowc + ROWC * GROUP + ROWI * GROUP;
-    double *olu = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + lane;  // [j * 64]
-    double *ojp = olu + NN * 64;                                                     // [j * 64]
+    constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
+    double *olu = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;  // [j * OS]
+    double *ojp = olu + NN * OS;                                                               // [j * OS]
     {   // cooperative load of the model image(s) and the row tables
         const int nthreads = WAVES_PER_BLOCK * 64;
         if (!per_inst) {
@@ -408,13 +410,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     wv::block_sync();
 
     const double *M = lds_img + (per_inst ? gib * L.total : 0);
-    double *qbuf = lds_scr + gib * S::SCRATCH;
-    double *ubuf = qbuf + S::QBUF;
+    double *ubuf = lds_scr + gib * S::SCRATCH;
     double *ybuf = ubuf + S::UBUF;
 
-    // zero this instance's scratch once: with a padded shape (nu_io < NU, nq < NQ) some
-    // u-tile / q-exchange entries are read but never written
-    for (int i = lig; i < S::SCRATCH; i += GROUP) qbuf[i] = 0.0;
+    // zero this instance's scratch once: with a padded shape (nu_io < NU) some u-tile entries
+    // are read but never written
+    for (int i = lig; i < S::SCRATCH; i += GROUP) ubuf[i] = 0.0;
     wv::wave_fence();
 
     // Which residual row (equation) this lane evaluates.  It starts as the host's row-order
@@ -426,7 +427,6 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         rd.kind = (lig < NN) ? lds_rowi[0 * GROUP + rowid] : RK_NONE;
         rd.erow = lds_rowi[1 * GROUP + rowid];
         rd.flags = lds_rowi[2 * GROUP + rowid];
-        sfor<0, 4>([&](auto tc_) ACME_LAMBDA { rd.tc[decltype(tc_)::value] = lds_rowi[(3 + decltype(tc_)::value) * GROUP + rowid]; });
         rd.rc = lds_rowc + rowid;
         sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
     };
@@ -469,10 +469,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         wv::sched_fence();
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
-            double acc = M[L.q0 + rd.tc[t]];
+            double acc = M[L.q0r + t * GROUP + rowid];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                acc = fma(M[L.pexp + j * NQ + rd.tc[t]], pb[j], acc);
+                acc = fma(M[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
             });
             pf[t] = acc;
         });
@@ -493,7 +493,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             double acc = pf[t];
             sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                acc = fma(M[L.fq + j * NQ + rd.tc[t]], zb[j], acc);
+                acc = fma(M[L.fqr + (t * NN + j) * GROUP + rowid], zb[j], acc);
             });
             e[t] = acc;
         });
@@ -505,10 +505,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         double chk = res * 0.0;
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * M[L.fq + j * NQ + rd.tc[0]];
+            double acc = tv[0] * M[L.fqr + j * GROUP + rowid];
             sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
-                acc = fma(tv[t], M[L.fq + j * NQ + rd.tc[t]], acc);
+                acc = fma(tv[t], M[L.fqr + (t * NN + j) * GROUP + rowid], acc);
             });
             a[j] = acc;
             chk = fma(acc, 0.0, chk);
@@ -522,10 +522,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     auto calc_jp = [&](double (&jp)[NPr]) ACME_LAMBDA {
         sfor<0, NP>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * M[L.pexp + j * NQ + rd.tc[0]];
+            double acc = tv[0] * M[L.pexpr + j * GROUP + rowid];
             sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
-                acc = fma(tv[t], M[L.pexp + j * NQ + rd.tc[t]], acc);
+                acc = fma(tv[t], M[L.pexpr + (t * NP + j) * GROUP + rowid], acc);
             });
             jp[j] = acc;
         });
@@ -551,10 +551,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         double dummy = 0.0;
         LU::template factor<false>(a, orig, lig, grp, dummy);
         adopt();
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * 64] = a[decltype(jc)::value]; });
         double jp0[NPr];
         calc_jp(jp0);
-        sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * 64] = jp0[decltype(jc)::value]; });
+        if (lig < NN) {
+            sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * OS] = a[decltype(jc)::value]; });
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp0[decltype(jc)::value]; });
+        }
         z = lz;
     }
 
@@ -567,9 +569,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         double t = 0.0;
         sfor<0, NP>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
-            t = fma(ojp[j * 64], wv::bcast16<j>(dp), t);
+            t = fma(ojp[j * OS], wv::bcast16<j>(dp), t);
         });
-        t = LU::solve([&](auto jc) ACME_LAMBDA { return olu[decltype(jc)::value * 64]; }, t, lig);
+        t = LU::solve([&](auto jc) ACME_LAMBDA { return olu[decltype(jc)::value * OS]; }, t, lig);
         z = sel(need, lz - t, z);
         bool act = need, conv = false;
         its = 0;
@@ -611,9 +613,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             if (wv::ballot(stop_conv)) {  // refresh the extrapolation origin (:231-234)
                 double jp[NPr];
                 calc_jp(jp);
-                if (stop_conv) {  // per-lane predicated LDS stores, no cross-lane ops inside
-                    sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * 64] = a[decltype(jc)::value]; });
-                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * 64] = jp[decltype(jc)::value]; });
+                if (stop_conv && lig < NN) {  // per-lane predicated LDS stores, no cross-lane ops inside
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * OS] = a[decltype(jc)::value]; });
+                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
                 }
                 lz = sel(stop_conv, z, lz);
                 lp = sel(stop_conv, target, lp);
@@ -645,8 +647,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     const int nu_io = A.nu_io, ny_io = A.ny_io;
     const double *ug = A.u + (valid ? inst : 0) * T * nu_io;
     double *yg = A.y + (valid ? inst : 0) * T * ny_io;
+    // u tile: fetched for chunk 0 before the loop and for chunk c+1 during the LAST sample of
+    // chunk c, after its Newton solve -- so the staging registers are not live across the
+    // (register-hungry) solver loop; the ~1 us of HBM latency hides behind that sample's y/x
+    // update and is paid once per 16 samples
     double upre[S::NUR];
-    auto prefetch_u = [&](long long n0) ACME_LAMBDA {
+    auto fetch_u = [&](long long n0) ACME_LAMBDA {
         long long cnt = T - n0;
         if (cnt > CHUNK) cnt = CHUNK;
         sfor<0, NU>([&](auto ic) ACME_LAMBDA {
@@ -655,20 +661,22 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             upre[i] = (valid && e < cnt * nu_io) ? ug[n0 * nu_io + e] : 0.0;
         });
     };
-    if (NU > 0) prefetch_u(0);
+    auto stage_u = [&]() ACME_LAMBDA {
+        wv::wave_fence();
+        sfor<0, NU>([&](auto ic) ACME_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            int e = lig + GROUP * i;
+            if (e < CHUNK * nu_io) ubuf[(e / nu_io) * NU + (e % nu_io)] = upre[i];
+        });
+        wv::wave_fence();
+    };
+    if (NU > 0) {
+        fetch_u(0);
+        stage_u();
+    }
 
     for (long long n0 = 0; n0 < T; n0 += CHUNK) {
         int cnt = (int)((T - n0 < CHUNK) ? (T - n0) : CHUNK);
-        if (NU > 0) {
-            wv::wave_fence();
-            sfor<0, NU>([&](auto ic) ACME_LAMBDA {
-                constexpr int i = decltype(ic)::value;
-                int e = lig + GROUP * i;
-                if (e < CHUNK * nu_io) ubuf[(e / nu_io) * NU + (e % nu_io)] = upre[i];
-            });
-            wv::wave_fence();
-            if (n0 + CHUNK < T) prefetch_u(n0 + CHUNK);
-        }
         for (int m = 0; m < cnt; ++m) {
             const long long n = A.sample_base + n0 + m;
             const bool alive = !dead;
@@ -735,6 +743,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 iters_total += alive ? its_sample : 0;
                 iters_max = (alive && its_sample > iters_max) ? its_sample : iters_max;
             }
+            if (NU > 0 && m == cnt - 1 && n0 + CHUNK < T) fetch_u(n0 + CHUNK);
             const bool live = !dead;
             // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
             if (NY > 0) {
@@ -797,6 +806,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 if (valid) yg[n0 * ny_io + e] = ybuf[(e / ny_io) * NY + (e % ny_io)];
             wv::wave_fence();
         }
+        if (NU > 0 && n0 + CHUNK < T) stage_u();
     }
 
     // ---- write back state and report ----------------------------------------------------

@@ -71,23 +71,30 @@ inline void kind_shape(int kind, int &nq, int &nn) {
 // (least padded work) shape that contains it
 inline bool choose_shape(const Dims &d, Dims &out) {
     const auto &list = shape_list();
-    long best = -1;
-    for (const Dims &s : list) {
-        if (d.rare && !s.rare) continue;
-        if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny) {
-            out = s;
-            return true;
+    // linear models prefer the solver-less shapes (pass 0); anything else, or a linear model
+    // too big for them, takes the cheapest shape that contains it (pass 1)
+    for (int pass = (d.nn == 0 ? 0 : 1); pass < 2; ++pass) {
+        long best = -1;
+        for (const Dims &s : list) {
+            if (d.rare && !s.rare) continue;
+            if (pass == 0 && s.nn != 0) continue;
+            if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny) {
+                out = s;
+                return true;
+            }
+            bool fits = d.nn <= s.nn && d.np <= s.np && d.nx <= s.nx && d.nu <= s.nu && d.ny <= s.ny &&
+                        d.nq + (s.nn - d.nn) <= s.nq;
+            if (!fits) continue;
+            long cost = (long)s.nn * s.nn * s.nn + (long)s.nq * (s.nn + s.np) +
+                        (long)(s.nx + s.np + s.ny) * (s.nx + s.nu + s.nn);
+            if (best < 0 || cost < best) {
+                best = cost;
+                out = s;
+            }
         }
-        bool fits = d.nn <= s.nn && d.np <= s.np && d.nx <= s.nx && d.nu <= s.nu && d.ny <= s.ny &&
-                    d.nq + (s.nn - d.nn) <= s.nq;
-        if (!fits) continue;
-        long cost = (long)s.nn * s.nn * s.nn + (long)s.nq * (s.nn + s.np) + (long)(s.nx + s.np + s.ny) * (s.nx + s.nu + s.nn);
-        if (best < 0 || cost < best) {
-            best = cost;
-            out = s;
-        }
+        if (best >= 0) return true;
     }
-    return best >= 0;
+    return false;
 }
 
 inline void put(std::vector<double> &img, int off, int ld, const std::vector<double> &m, int r, int c) {
@@ -136,7 +143,8 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     }
     P.shape = S;
     P.actual = d;
-    const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny);
+    const int NT = S.rare ? 4 : 3;
+    const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny, NT);
     P.image.assign(L.total, 0.0);
     put(P.image, L.a, S.nx, m.a, d.nx, d.nx);
     put(P.image, L.b, S.nx, m.b, d.nx, d.nu);
@@ -153,9 +161,6 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         put(P.image, L.fy, S.ny, m.fy, d.ny, d.nn);
         put(P.image, L.dq, S.np, s->dq, d.np, d.nx);
         put(P.image, L.eq, S.np, s->eq, d.np, d.nu);
-        put(P.image, L.pexp, S.nq, s->pexp, d.nq, d.np);
-        put(P.image, L.fq, S.nq, s->fq, d.nq, d.nn);
-        put(P.image, L.q0, S.nq, s->q0, d.nq, 1);
         for (int i = 0; i < d.nn; ++i) P.init_state[S.nx + S.np + i] = s->init_z[i];
         std::vector<int> pos_of(d.nn);
         for (int i = 0; i < d.nn; ++i) pos_of[i] = i;
@@ -275,12 +280,27 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         }
     }
     // shape padding: extra unknowns z_pad with the trivial equation q_pad = z_pad = 0
+    std::vector<double> fqp((size_t)S.nq * S.nn, 0.0), pexpp((size_t)S.nq * S.np, 0.0), q0p(S.nq, 0.0);
+    if (s) {
+        put(fqp, 0, S.nq, s->fq, d.nq, d.nn);
+        put(pexpp, 0, S.nq, s->pexp, d.nq, d.np);
+        put(q0p, 0, S.nq, s->q0, d.nq, 1);
+    }
     for (int r = d.nn; r < S.nn; ++r) {
         int qrow = d.nq + (r - d.nn);
-        P.image[L.fq + (size_t)r * S.nq + qrow] = 1.0;
+        fqp[(size_t)r * S.nq + qrow] = 1.0;
         P.rowi[0 * GROUP + r] = RK_PAD;
         for (int t = 0; t < 4; ++t) P.rowi[(3 + t) * GROUP + r] = qrow;
     }
+    // row-gathered copies of fq / pexp / q0 (see Layout): slot `pos` = the lane position of
+    // the residual row, term t = its t-th Jq non-zero
+    for (int pos = 0; pos < S.nn; ++pos)
+        for (int t = 0; t < NT; ++t) {
+            int tc = P.rowi[(3 + t) * GROUP + pos];
+            for (int j = 0; j < S.nn; ++j) P.image[L.fqr + ((size_t)t * S.nn + j) * GROUP + pos] = fqp[(size_t)j * S.nq + tc];
+            for (int j = 0; j < S.np; ++j) P.image[L.pexpr + ((size_t)t * S.np + j) * GROUP + pos] = pexpp[(size_t)j * S.nq + tc];
+            P.image[L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
+        }
     return true;
 }
 

@@ -5,7 +5,7 @@ export PYTHONPATH=$ROOT; cd /tmp; export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 1 --samples 2205 $*"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS -d $OUT/a -o b -- $BENCH > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 -d $OUT/b -o b -- $BENCH > $OUT/b.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_VALU_MFMA_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_INSTS_SENDMSG -d $OUT/c -o b -- $BENCH > $OUT/c.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_BRANCH SQ_LDS_MEM_VIOLATIONS -d $OUT/c -o b -- $BENCH > $OUT/c.log 2>&1
 python - $OUT <<'PY'
 import sqlite3, glob, sys
 for f in sorted(glob.glob(sys.argv[1] + "/*/b_results.db")):

@@ -23,22 +23,26 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY S
 echo "== pmc: SQ2 (instruction mix)"
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_sq2" -o bench -- $BENCH > "$OUT/pmc_sq2.log" 2>&1
-find "$OUT" -name "*.csv" | head -40
 python - "$OUT" <<'PY'
 import csv, glob, sys, os, collections
 out = sys.argv[1]
-for f in sorted(glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)):
-    print("--", f)
-    print(open(f).read()[:3000])
+import sqlite3
+# rocprofv3 (ROCm 7.2) writes rocpd sqlite databases; summarise them as text
+for f in sorted(glob.glob(out + "/trace/*.db")):
+    con = sqlite3.connect(f)
+    print("== kernel trace / stats (", os.path.basename(os.path.dirname(f)), ")")
+    print("%-70s %6s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    for r in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 6"):
+        print("%-70s %6d %14.1f %14.1f %8.3f" % (r[0][:70], r[1], r[2] / 1e3, r[3] / 1e3, r[4]))
+    for r in con.execute("select name, count(*), avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, max(vgpr_count), "
+                         "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) "
+                         "from kernels where name like '%acme%' group by name"):
+        print("dispatches=%d avg_us=%.1f min_us=%.1f max_us=%.1f vgpr=%s agpr=%s sgpr=%s lds_bytes=%s scratch=%s grid=%s wg=%s" % r[1:])
 for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    for f in sorted(glob.glob(out + f"/{grp}/**/*counter_collection.csv", recursive=True)):
-        acc = collections.defaultdict(lambda: [0.0, 0])
-        for row in csv.DictReader(open(f)):
-            k = (row.get("Kernel_Name", "")[:60], row.get("Counter_Name", ""))
-            acc[k][0] += float(row.get("Counter_Value", 0) or 0)
-            acc[k][1] += 1
-        print("--", f)
-        for (kn, cn), (v, n) in sorted(acc.items()):
-            if "acme" in kn:
-                print(f"{kn:60s} {cn:24s} sum={v:.6g} dispatches={n} per_dispatch={v / max(n, 1):.6g}")
+    for f in sorted(glob.glob(out + f"/{grp}/*.db")):
+        con = sqlite3.connect(f)
+        print("== counters", grp)
+        for r in con.execute("select counter_name, count(*), avg(value) from counters_collection "
+                             "where kernel_name like '%acme%' group by counter_name"):
+            print("%-28s dispatches=%d per_dispatch=%.6g" % r)
 PY
