@@ -87,6 +87,34 @@ template <int K, int N> ACME_DEV bool lig_in() {                                
 }
 
 ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
+
+// exp(x) for the junction laws: k = rint(x*log2(e)), r = x - k*ln2 (two-part Cody-Waite),
+// degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18 relative), scale by 2^k with
+// ldexp (which also saturates to inf / flushes to 0 for out-of-range arguments).  About 1 ulp,
+// 19 instructions with two short dependency chains instead of the ~40 of the general-purpose
+// library routine.  exp(+-inf) gives NaN here (the library gives inf / 0): both make the residual
+// non-finite only in states the solver has already lost.
+ACME_DEV double exp_junction(double x) {
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;        // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);      // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);     // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);     // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);    // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);      // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);     // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);     // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);     // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);    // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);    // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double kc = fmin(fmax(k, -2100.0), 2100.0);
+    return ldexp(p, (int)kc);
+}
 ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 
 // ---------------------------------------------------------------------------------------
@@ -499,8 +527,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         });
         // hoisted exponentials: diode exp(v/(eta vT)), BJT exp(vE/..), exp(vC/..)
         const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
-        double exA = exp(expo ? e[0] * rd.k[0] : 0.0);
-        double exB = has_bjt ? exp(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0) : 1.0;
+        double exA = exp_junction(expo ? e[0] * rd.k[0] : 0.0);
+        double exB = has_bjt ? exp_junction(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0) : 1.0;
         eval_row<S::RARE, NT>(rd, e, exA, exB, res, tv);
         double chk = res * 0.0;
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
@@ -581,8 +609,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             for (int r_ = 0; r_ < A.prof[0]; ++r_) { (void)evaluate(z + 1e-30 * r_); prof_sink += res + a[0]; }
 #endif
             bool finite = evaluate(z);
-            double rm = wv::allmax16(lig_lt<NN>() ? fabs(res) : 0.0);
-            ACME_DBG("  it %d lane %d act %d z %.17g res %.17g J0 %.17g finite %d rm %g", its, lane, (int)act, z, res, a[0], (int)finite, rm);
+            // hasconverged (resmaxabs < tol, src/solvers.jl:203): only the boolean is needed, so
+            // no max-reduction -- one compare and a ballot; a NaN residual counts as not small
+            const unsigned long long big = wv::ballot(!(fabs(res) < A.tol)) & rows4((1ull << NN) - 1ull);
             // LU before the convergence test (:223-226); res rides along as an augmented
             // column, so `fwd` = L^-1 P res when the factorisation is done.  First try the
             // branch-free in-place elimination; only if some instance of this wave needed a
@@ -595,7 +624,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 ok = LU::template factor<true>(a, orig, lig, grp, fwd);
                 adopt();
             }
-            bool small = rm < A.tol;
+            bool small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
 #ifdef ACME_PROFILE_PIECES  // repeat single pieces in situ (results unchanged) to time them
             for (int r_ = 0; r_ < A.prof[1]; ++r_) {
                 double a2[NNr];
