@@ -97,6 +97,14 @@ struct KArgs {
     int has_bjt;             // any BJT row -> second exp needed
     int rare_kinds;          // any MOSFET/MACAK/JA row
     int prof[4];             // only read by ACME_PROFILE_PIECES builds (tools/profile_pieces.py)
+    // solver-plugin mode (acme_batch_solve): if p_in != nullptr the launch performs ONE
+    // solve(solver, p) per instance instead of running samples: p comes from p_in, the
+    // solution / hasconverged / needediterations go to z_out / conv_out / iters_out, x is
+    // not touched, the extrapolation origin is updated as by any solve
+    const double *p_in;      // [n_inst][np_io]
+    double *z_out;           // [n_inst][nn_io]
+    int *conv_out, *iters_out;
+    int np_io, nn_io;
 };
 
 }  // namespace acme

@@ -672,7 +672,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     }
 
     // ---- time loop ----------------------------------------------------------------------
-    const long long T = A.T;
+    const bool solve_mode = A.p_in != nullptr;
+    const long long T = solve_mode ? 1 : A.T;
     const int nu_io = A.nu_io, ny_io = A.ny_io;
     const double *ug = A.u + (valid ? inst : 0) * T * nu_io;
     double *yg = A.y + (valid ? inst : 0) * T * ny_io;
@@ -699,7 +700,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         });
         wv::wave_fence();
     };
-    if (NU > 0) {
+    if (NU > 0 && !solve_mode) {
         fetch_u(0);
         stage_u();
     }
@@ -722,6 +723,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     constexpr int k = decltype(kc)::value;
                     p = fma(M[L.eq + k * NP + lig], ubuf[m * NU + k], p);
                 });
+                if (solve_mode) p = (valid && lig < A.np_io) ? A.p_in[inst * A.np_io + lig] : 0.0;
                 // solve(::HomotopySolver, p) (src/solvers.jl:268-296) as a per-instance
                 // state machine; every base solve is shared by the wave
                 bool need = alive, conv = false;
@@ -757,6 +759,14 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     }
                 }
                 zfin = z;
+                if (solve_mode) {   // hand the solver's answer back; no y, no state update
+                    if (valid && lig < A.nn_io) A.z_out[inst * A.nn_io + lig] = z;
+                    if (valid && lig == 0) {
+                        A.conv_out[inst] = conv ? 1 : 0;
+                        A.iters_out[inst] = its_sample;
+                    }
+                    continue;
+                }
                 // convergence policy of step! (src/ACME.jl:688-694)
                 unsigned long long nf = wv::ballot(lig < NN && !(z * 0.0 == 0.0));
                 bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
@@ -829,7 +839,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             }
         }
         // flush the y tile, coalesced
-        if (NY > 0) {
+        if (NY > 0 && !solve_mode) {
             wv::wave_fence();
             for (int e = lig; e < cnt * ny_io; e += GROUP)
                 if (valid) yg[n0 * ny_io + e] = ybuf[(e / ny_io) * NY + (e % ny_io)];
@@ -847,7 +857,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         });
         if (NP > 0 && lig < NP) st[NX + lig] = lp;
         if (NN > 0 && lig < NN) st[NX + NP + lig] = lz;
-        if (lig == 0) {
+        if (lig == 0 && !solve_mode) {
             long long *rp = A.report + inst * RW_WORDS;
             rp[RW_NWARN] = n_warn;
             rp[RW_FIRST_NONCONV] = first_nonconv;

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
-    "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
+    "acme_batch_solve", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
 
@@ -108,6 +108,7 @@ class Library:
         L.acme_batch_destroy.restype = None
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
+        L.acme_batch_solve.argtypes = [vp, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.acme_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
         L.acme_batch_get_report.argtypes = [vp, C.POINTER(Report)]
@@ -342,6 +343,19 @@ class ModelRunner:
     def set_resabstol(self, tol):
         """``set_resabstol!`` (src/solvers.jl:181,262)."""
         self.lib.check(self.lib.L.acme_batch_set_resabstol(self.h, float(tol)))
+
+    def solve(self, p):
+        """Batched ``solve(solver, p)`` (src/solvers.jl:207-236, 268-302): ``p`` is (N, np);
+        returns ``(z, hasconverged, needediterations)`` with shapes (N, nn), (N,), (N,).  Uses
+        and updates each instance's extrapolation origin like the reference's solver objects."""
+        s = self.model.subs[0]
+        p = np.ascontiguousarray(np.broadcast_to(np.asarray(p, dtype=np.float64), (self.n, s.np)))
+        z = np.zeros((self.n, s.nn))
+        conv = np.zeros(self.n, dtype=np.int32)
+        iters = np.zeros(self.n, dtype=np.int32)
+        self.lib.check(self.lib.L.acme_batch_solve(self.h, _dp(p), _dp(z), _ip(conv), _ip(iters),
+                                                   ACME_MEM_HOST, None))
+        return z, conv.astype(bool), iters
 
     def get_state(self):
         """(x, last_p, last_z): model.x and the extrapolation origin of every instance."""

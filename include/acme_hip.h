@@ -128,6 +128,14 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
                    void *stream);
 
+/* The solver plugin contract, batched (src/solvers.jl:207-236, 268-302): for every instance
+ *   z = solve(solver, p); converged = hasconverged(solver); iters = needediterations(solver)
+ * p is [N][np], z is [N][nn] (sub-problem 0), converged/iters are [N].  Like the reference's
+ * solver objects the call uses and updates the instance's extrapolation origin; x is not
+ * touched and nothing is added to the run reports.  mem/stream as for acme_batch_run. */
+int acme_batch_solve(acme_batch *b, const double *p, double *z, int *converged, int *iters,
+                     int mem, void *stream);
+
 /* milliseconds the last acme_batch_run kernel took on the device (HIP events recorded on
  * the launch stream); synchronises with that launch */
 int acme_batch_last_kernel_ms(acme_batch *b, float *ms);

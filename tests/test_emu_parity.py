@@ -117,3 +117,84 @@ def test_emulated_tight_tolerance_parity(emu_lib):
         rr = RefRunner(m)
         rr.set_resabstol(1e-13)
         assert_close(y[i:i + 1], rr.run(u[i])[None], rtol=RTOL_TIGHT)
+
+
+def test_emulated_solver_plugin_contract(emu_lib):
+    """solve / hasconverged / needediterations / extrapolation origin (src/solvers.jl:183-236,
+    268-302) through acme_batch_solve, against the oracle's solver object."""
+    from oracle.refpy import RefRunner
+    rng = np.random.default_rng(3)
+    for name in ("diodeclipper", "birdie_var"):
+        m = load(name)
+        s = m.subs[0]
+        N = 6
+        r = emu_runner(emu_lib, m, N)
+        refs = [RefRunner(m) for _ in range(N)]
+        for step in range(4):   # consecutive solves: the origin carries over
+            p = rng.normal(scale=0.3, size=(N, s.np))
+            z, conv, its = r.solve(p)
+            for i in range(N):
+                zr, cr, ir = refs[i].solve(p[i])
+                assert conv[i] == cr, (name, step, i)
+                # plain Newton solves take identical iteration counts; once the homotopy
+                # wrapper has to bisect, rounding-level differences change the path
+                if ir <= 20:
+                    assert its[i] == ir, (name, step, i, its[i], ir)
+                np.testing.assert_allclose(z[i], zr, rtol=1e-7, atol=1e-10)
+        x, lp, lz = r.get_state()
+        for i in range(N):
+            pr, zr = refs[i].get_origin(0)
+            np.testing.assert_allclose(lp[i], pr, rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(lz[i], zr, rtol=1e-9, atol=1e-12)
+        assert not x.any()      # solve() never touches the state vector
+
+
+def test_emulated_homotopy_needed_and_failure(emu_lib):
+    """A solve that only the homotopy wrapper rescues, and one with no solution
+    (test/runtests.jl:207-219 in spirit, :170-183)."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel, SimpleSolver
+    from oracle.refpy import RefRunner
+    m = DiscreteModel(circuits.no_solution_circuit(), Fraction(1))
+    r = emu_runner(emu_lib, m, 3)
+    p = np.array([[1.0], [-1.0], [50.0]]) / m.subs[0].eq[0, 0] * m.subs[0].eq[0, 0]
+    z, conv, its = r.solve(p)
+    for i in range(3):
+        zr, cr, ir = RefRunner(m).solve(p[i])
+        assert conv[i] == cr and its[i] == ir
+    ms = DiscreteModel(circuits.no_solution_circuit(), Fraction(1), solver=SimpleSolver)
+    z2, conv2, its2 = emu_runner(emu_lib, ms, 3).solve(p)
+    for i in range(3):
+        zr, cr, ir = RefRunner(ms).solve(p[i])
+        assert conv2[i] == cr and its2[i] == ir
+
+
+def test_emulated_checksteady(emu_lib):
+    """checksteady! (test/runtests.jl:664-671): steadystate!, tolerance 1e-13, one zero-input
+    step must leave x unchanged -- for diodeclipper, birdie (fixed), superover (fixed)."""
+    from acme_jl_amd.analysis import steadystate_
+    for name in ("diodeclipper", "birdie_fixed", "superover_fixed"):
+        m = load(name)
+        r = emu_runner(emu_lib, m, 2)
+        xs = steadystate_(r)
+        r.set_resabstol(1e-13)
+        r.run(np.zeros((2, m.nu, 1)))
+        x, _, _ = r.get_state()
+        np.testing.assert_allclose(x, xs, rtol=1.5e-8, atol=1e-14)
+        if name != "diodeclipper":
+            assert np.abs(xs).max() > 1e-4      # a real bias point (c5 charged to 9 V), not the zero state
+
+
+def test_emulated_steadystate_per_instance_inputs(emu_lib):
+    """N different operating points in one batched solve (per-instance derived equations)."""
+    from acme_jl_amd.analysis import steadystate
+    m = load("birdie_var")
+    U = np.array([[0.0, 0.2], [0.0, 0.9], [0.1, 0.5]])
+    X = steadystate(m, U, lib=emu_lib)
+    r = emu_runner(emu_lib, m, 3)
+    r.set_state(x=X)
+    r.set_resabstol(1e-13)
+    r.run(np.repeat(U[:, :, None], 1, axis=2))
+    x, _, _ = r.get_state()
+    np.testing.assert_allclose(x, X, rtol=1.5e-8, atol=1e-14)

@@ -201,3 +201,38 @@ def test_full_size_properties(hip_lib):
     idx = np.linspace(0, N - 1, 8).astype(int)
     yref, _ = oracle_run(m, u[idx].cpu().numpy().transpose(0, 2, 1))
     assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
+
+
+def test_solver_plugin_contract(hip_lib):
+    """acme_batch_solve vs the oracle's solver object (solve/hasconverged/needediterations,
+    extrapolation origin; src/solvers.jl:183-236, 268-302)."""
+    from oracle.refpy import RefRunner
+    rng = np.random.default_rng(3)
+    for name in ("diodeclipper", "superover_fixed"):
+        m = load(name)
+        s = m.subs[0]
+        N = 40
+        r = runner(hip_lib, m, N)
+        refs = [RefRunner(m) for _ in range(N)]
+        for step in range(3):
+            p = rng.normal(scale=0.05, size=(N, s.np))
+            z, conv, its = r.solve(p)
+            for i in range(N):
+                zr, cr, ir = refs[i].solve(p[i])
+                assert conv[i] == cr
+                if ir <= 20:
+                    assert its[i] == ir
+                np.testing.assert_allclose(z[i], zr, rtol=1e-7, atol=1e-10)
+
+
+def test_checksteady(hip_lib):
+    """test/runtests.jl:664-671 for the example models (:703,728,748)."""
+    from acme_jl_amd.analysis import steadystate_
+    for name in ("diodeclipper", "birdie_fixed", "superover_fixed"):
+        m = load(name)
+        r = runner(hip_lib, m, 3)
+        xs = steadystate_(r)
+        r.set_resabstol(1e-13)
+        r.run(np.zeros((3, m.nu, 1)))
+        x, _, _ = r.get_state()
+        np.testing.assert_allclose(x, xs, rtol=1.5e-8, atol=1e-14)
