@@ -23,7 +23,7 @@ constexpr int INST_PER_BLOCK = GROUPS_PER_WAVE * WAVES_PER_BLOCK;
 constexpr int CHUNK = 16;         // samples staged per coalesced u/y transfer
 constexpr int ROWC = 24;          // precomputed constants per residual row
 constexpr int ROWI = 8;           // ints per residual row: kind, erow, flags, tc[0..3], (spare)
-constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8;
+constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8, MAX_NSUB = 4;
 
 // residual-row kinds (element kind of the row's element; same numbering as the element
 // kinds of include/acme_hip.h, plus PAD for rows added by host-side shape padding)
@@ -37,37 +37,48 @@ enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1 };
 struct Dims {
     int nn, nq, np, nx, nu, ny;
     int rare;  // shape compiled with / model needs the MOSFET, tanh op-amp, JA kinds
+    int nsub;  // nonlinear sub-problems (shape: capacity; model: actual count)
 };
 
 // offsets (in doubles) of each matrix inside a model image
+// Model image = [shared part][sub-problem 0][sub-problem 1]...  Every sub-problem is padded to
+// the shape's (nn, nq, np); the unknowns of sub-problem s occupy z columns s*nn .. s*nn+nn-1.
 // pexps/fqs/q0s are stored ROW-GATHERED: for residual row r and its t-th Jq non-zero (q row
 // tc[r][t]) the image holds  fqr[(t*nn + j)*16 + r] = fq[tc[r][t], j]  (likewise pexpr, q0r).
 // The lane that evaluates row r then reads consecutive addresses for fixed (t, j): no
 // indirection and no LDS bank conflicts (the plain fq[tc + j*nq] form was ~39 % conflicts).
 struct Layout {
-    int dq, eq, pexpr, fqr, q0r, a, b, c, x0, dy, ey, fy, y0, total;
+    int a, b, c, x0, dy, ey, fy, y0;            // shared, absolute offsets
+    int sub0, sub_stride;                       // first sub-problem block, distance to the next
+    int dq, eq, fqprev, pexpr, fqr, q0r;        // offsets relative to a sub-problem block
+    int total;
 };
 
-ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int ny, int nt) {
+ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int ny, int nt, int nsub) {
     Layout L{};
-    int o = 0;
     (void)nq;
-    L.dq = o;    o += np * nx;
-    L.eq = o;    o += np * nu;
-    L.pexpr = o; o += nt * np * GROUP;
-    L.fqr = o;   o += nt * nn * GROUP;
-    L.q0r = o;   o += nt * GROUP;
+    const int nz = nsub * nn;
+    int o = 0;
     L.a = o;    o += nx * nx;
     L.b = o;    o += nx * nu;
-    L.c = o;    o += nx * nn;
+    L.c = o;    o += nx * nz;
     L.x0 = o;   o += nx;
     L.dy = o;   o += ny * nx;
     L.ey = o;   o += ny * nu;
-    L.fy = o;   o += ny * nn;
+    L.fy = o;   o += ny * nz;
     L.y0 = o;   o += ny;
-    // tail padding: lanes beyond a matrix's row count read (finite) neighbours, never
-    // past the end of the image
-    o += 2 * GROUP;
+    L.sub0 = (o + 1) & ~1;
+    int r = 0;
+    L.dq = r;     r += np * nx;
+    L.eq = r;     r += np * nu;
+    L.fqprev = r; r += np * nz;
+    L.pexpr = r;  r += nt * np * GROUP;
+    L.fqr = r;    r += nt * nn * GROUP;
+    L.q0r = r;    r += nt * GROUP;
+    L.sub_stride = (r + 1) & ~1;
+    // tail padding: lanes beyond a matrix's row count read (finite) neighbours, never past
+    // the end of the image
+    o = L.sub0 + nsub * L.sub_stride + 2 * GROUP;
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -105,6 +116,8 @@ struct KArgs {
     double *z_out;           // [n_inst][nn_io]
     int *conv_out, *iters_out;
     int np_io, nn_io;
+    int solve_sub;           // sub-problem acme_batch_solve addresses
+    int nsub;                // actual number of sub-problems (<= the shape's NSUB)
 };
 
 }  // namespace acme

@@ -43,11 +43,11 @@ template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t
 
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
-#define ACME_X(nn, nq, np, nx, nu, ny, rare)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare>>, \
-                Shape<nn, nq, np, nx, nu, ny, rare>::lds_doubles(false),                                   \
-                Shape<nn, nq, np, nx, nu, ny, rare>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare>::STATE,  \
-                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare>>},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>, \
+                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
+                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
+                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -56,7 +56,7 @@ static const std::vector<KernelEntry> &kernel_table() {
 
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
-        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare)
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub)
             return &k;
     return nullptr;
 }

@@ -37,27 +37,33 @@
 
 namespace acme {
 
-template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0> struct Shape {
+template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, int NSUB_ = 1> struct Shape {
     static constexpr int NN = NN_, NQ = NQ_, NP = NP_, NX = NX_, NU = NU_, NY = NY_;
+    // NSUB: capacity for nonlinear sub-problems solved one after another each sample
+    // (src/ACME.jl:675-697); every sub-problem is padded to (NN, NQ, NP)
+    static constexpr int NSUB = NN_ > 0 ? NSUB_ : 0;
+    static constexpr int NSUBr = NSUB > 0 ? NSUB : 1;
     // RARE: the MOSFET / tanh op-amp / Jiles-Atherton element functions are compiled in
     static constexpr bool RARE = RARE_ != 0;
     static constexpr int NT = RARE ? 4 : 3;  // max Jq non-zeros of one residual row
     static constexpr int NQS = (NQ + GROUP - 1) / GROUP;  // q rows per lane
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
-    static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY, RARE_ != 0 ? 4 : 3);
+    static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY, RARE_ != 0 ? 4 : 3, NSUBr);
     // per-instance LDS scratch (doubles): u tile | y tile
     static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY;
     static constexpr int SCRATCH = (UBUF + YBUF + 2) & ~1;
-    static constexpr int STATE = NX + NP + NN;  // doubles of persistent state per instance
+    // persistent state per instance: x | last_p of every sub-problem | last_z of every sub-problem
+    static constexpr int STATE = NX + NSUBr * (NP + NN);
     // per-wave store of the extrapolation origin's LU factors and Jp: one slab per matrix
     // column holding the NN rows of each of the wave's 4 instances back to back (lane r keeps
     // row r: consecutive addresses, conflict-free ds_read/write_b64).  LDS per block decides
     // whether 2 blocks (= 2 waves/SIMD) fit a CU, so the slabs are packed to NN rows, not 16.
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
-    static constexpr int ORIGIN = (NN + NP) * OSTRIDE + GROUP;
+    static constexpr int ORIGIN1 = (NN + NP) * OSTRIDE;       // one sub-problem
+    static constexpr int ORIGIN = NSUBr * ORIGIN1 + GROUP;
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
-        return (per_instance ? INST_PER_BLOCK : 1) * L.total + ROWC * GROUP + ROWI * GROUP +
+        return (per_instance ? INST_PER_BLOCK : 1) * L.total + NSUBr * (ROWC * GROUP + ROWI * GROUP) +
                INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
 };
@@ -398,7 +404,7 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, dou
 // ---------------------------------------------------------------------------------------
 template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
-    constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT;
+    constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT, NSUB = S::NSUBr;
     constexpr int NNr = NN > 0 ? NN : 1, NPr = NP > 0 ? NP : 1, NQSr = NQS > 0 ? NQS : 1,
                   NXSr = NXS > 0 ? NXS : 1;
     constexpr Layout L = S::L;
@@ -414,12 +420,16 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
 
     // ---- LDS carve-up -------------------------------------------------------------------
     double *lds_img = lds;
-    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;
-    int *lds_rowi = (int *)(lds_rowc + ROWC * GROUP);
-    double *lds_scr = lds_rowc + ROWC * GROUP + ROWI * GROUP;
+    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;        // [NSUB][ROWC*16]
+    int *lds_rowi = (int *)(lds_rowc + NSUB * ROWC * GROUP);                       // [NSUB][ROWI*16]
+    double *lds_scr = lds_rowc + NSUB * (ROWC * GROUP + ROWI * GROUP);
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
-    double *olu = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;  // [j * OS]
-    double *ojp = olu + NN * OS;                                                               // [j * OS]
+    double *const olu0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;
+    // context of the sub-problem being solved (switched by enter_sub)
+    double *olu = olu0;            // origin factors  [j * OS]
+    double *ojp = olu0 + NN * OS;  // origin Jp       [j * OS]
+    const double *rowc_s = lds_rowc;
+    const int *rowi_s = lds_rowi;
     {   // cooperative load of the model image(s) and the row tables
         const int nthreads = WAVES_PER_BLOCK * 64;
         if (!per_inst) {
@@ -432,12 +442,13 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 for (int i = tid; i < L.total; i += nthreads) lds_img[g * L.total + i] = src[i];
             }
         }
-        for (int i = tid; i < ROWC * GROUP; i += nthreads) lds_rowc[i] = A.rowc[i];
-        for (int i = tid; i < ROWI * GROUP; i += nthreads) lds_rowi[i] = A.rowi[i];
+        for (int i = tid; i < NSUB * ROWC * GROUP; i += nthreads) lds_rowc[i] = A.rowc[i];
+        for (int i = tid; i < NSUB * ROWI * GROUP; i += nthreads) lds_rowi[i] = A.rowi[i];
     }
     wv::block_sync();
 
-    const double *M = lds_img + (per_inst ? gib * L.total : 0);
+    const double *M = lds_img + (per_inst ? gib * L.total : 0);   // this instance's image
+    const double *Ms = M + L.sub0;                                // current sub-problem block
     double *ubuf = lds_scr + gib * S::SCRATCH;
     double *ybuf = ubuf + S::UBUF;
 
@@ -452,10 +463,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     int rowid = lig;
     RowDesc rd;
     auto load_rowdesc = [&]() ACME_LAMBDA {
-        rd.kind = (lig < NN) ? lds_rowi[0 * GROUP + rowid] : RK_NONE;
-        rd.erow = lds_rowi[1 * GROUP + rowid];
-        rd.flags = lds_rowi[2 * GROUP + rowid];
-        rd.rc = lds_rowc + rowid;
+        rd.kind = (lig < NN) ? rowi_s[0 * GROUP + rowid] : RK_NONE;
+        rd.erow = rowi_s[1 * GROUP + rowid];
+        rd.flags = rowi_s[2 * GROUP + rowid];
+        rd.rc = rowc_s + rowid;
         sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
     };
     load_rowdesc();
@@ -482,8 +493,19 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         int i = s * GROUP + lig;
         x[s] = (valid && i < NX) ? st[i] : 0.0;
     });
-    if (NP > 0) lp = (valid && lig < NP) ? st[NX + lig] : 0.0;
-    if (NN > 0) lz = (valid && lig < NN) ? st[NX + NP + lig] : 0.0;
+    // saved context of every sub-problem: its extrapolation origin, its current lane->row
+    // assignment and its latest solution; (lp, lz, rowid, ...) above are the live copies of
+    // the sub-problem being solved
+    double lps[NSUB], lzs[NSUB], zs[NSUB];
+    int rowids[NSUB];
+    sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
+        constexpr int s = decltype(sc)::value;
+        lps[s] = (NP > 0 && valid && lig < NP) ? st[NX + s * NP + lig] : 0.0;
+        lzs[s] = (NN > 0 && valid && lig < NN) ? st[NX + NSUB * NP + s * NN + lig] : 0.0;
+        zs[s] = 0.0;
+        rowids[s] = lig;
+    });
+    const int nsub = (NN > 0) ? A.nsub : 0;
 
 #ifdef ACME_PROFILE_PIECES
     double prof_sink = 0.0;
@@ -497,10 +519,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         wv::sched_fence();
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
-            double acc = M[L.q0r + t * GROUP + rowid];
+            double acc = Ms[L.q0r + t * GROUP + rowid];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                acc = fma(M[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
+                acc = fma(Ms[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
             });
             pf[t] = acc;
         });
@@ -521,7 +543,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             double acc = pf[t];
             sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                acc = fma(M[L.fqr + (t * NN + j) * GROUP + rowid], zb[j], acc);
+                acc = fma(Ms[L.fqr + (t * NN + j) * GROUP + rowid], zb[j], acc);
             });
             e[t] = acc;
         });
@@ -533,10 +555,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         double chk = res * 0.0;
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * M[L.fqr + j * GROUP + rowid];
+            double acc = tv[0] * Ms[L.fqr + j * GROUP + rowid];
             sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
-                acc = fma(tv[t], M[L.fqr + (t * NN + j) * GROUP + rowid], acc);
+                acc = fma(tv[t], Ms[L.fqr + (t * NN + j) * GROUP + rowid], acc);
             });
             a[j] = acc;
             chk = fma(acc, 0.0, chk);
@@ -550,10 +572,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     auto calc_jp = [&](double (&jp)[NPr]) ACME_LAMBDA {
         sfor<0, NP>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * M[L.pexpr + j * GROUP + rowid];
+            double acc = tv[0] * Ms[L.pexpr + j * GROUP + rowid];
             sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
-                acc = fma(tv[t], M[L.pexpr + (t * NP + j) * GROUP + rowid], acc);
+                acc = fma(tv[t], Ms[L.pexpr + (t * NP + j) * GROUP + rowid], acc);
             });
             jp[j] = acc;
         });
@@ -571,22 +593,48 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         load_rowdesc();
     };
 
+    // switch the live solver context to sub-problem s / save it back
+    auto enter_sub = [&](auto sc) ACME_LAMBDA {
+        constexpr int s = decltype(sc)::value;
+        Ms = M + L.sub0 + s * L.sub_stride;
+        rowc_s = lds_rowc + s * ROWC * GROUP;
+        rowi_s = lds_rowi + s * ROWI * GROUP;
+        olu = olu0 + s * S::ORIGIN1;
+        ojp = olu + NN * OS;
+        lp = lps[s];
+        lz = lzs[s];
+        rowid = rowids[s];
+        load_rowdesc();
+    };
+    auto leave_sub = [&](auto sc) ACME_LAMBDA {
+        constexpr int s = decltype(sc)::value;
+        lps[s] = lp;
+        lzs[s] = lz;
+        rowids[s] = rowid;
+    };
+
     // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196): the factors and Jp
     // at the origin are recomputed from (p, z), so only (p, z) has to persist in HBM.
-    if (NN > 0) {
-        set_p(lp);
-        evaluate(lz);
-        double dummy = 0.0;
-        LU::template factor<false>(a, orig, lig, grp, dummy);
-        adopt();
-        double jp0[NPr];
-        calc_jp(jp0);
-        if (lig < NN) {
-            sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * OS] = a[decltype(jc)::value]; });
-            sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp0[decltype(jc)::value]; });
+    sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
+        constexpr int s = decltype(sc)::value;
+        if (NN > 0 && s < nsub) {
+            enter_sub(sc);
+            set_p(lp);
+            evaluate(lz);
+            double dummy = 0.0;
+            LU::template factor<false>(a, orig, lig, grp, dummy);
+            adopt();
+            double jp0[NPr];
+            calc_jp(jp0);
+            if (lig < NN) {
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * OS] = a[decltype(jc)::value]; });
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp0[decltype(jc)::value]; });
+            }
+            z = lz;
+            leave_sub(sc);
         }
-        z = lz;
-    }
+    });
+    if (S::NSUB == 1) enter_sub(std::integral_constant<int, 0>{});   // stays entered for the whole launch
 
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
     // returns hasconverged, leaves needediterations in `its`.
@@ -709,19 +757,31 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         int cnt = (int)((T - n0 < CHUNK) ? (T - n0) : CHUNK);
         for (int m = 0; m < cnt; ++m) {
             const long long n = A.sample_base + n0 + m;
-            const bool alive = !dead;
-            double zfin = 0.0;
-            if (NN > 0) {
-                // p = dq*x + eq*u  (src/ACME.jl:678-683)
+            // the nonlinear sub-problems, one after another: later ones see the solutions of the
+            // earlier ones through fqprev (src/ACME.jl:675-697)
+            sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
+                constexpr int s = decltype(sc)::value;
+                if (!(NN > 0 && s < nsub)) return;
+                if (solve_mode && s != A.solve_sub) return;
+                if (S::NSUB > 1) enter_sub(sc);
+                const bool alive = !dead;
+                // p = dq*x + eq*u + fqprev*z  (src/ACME.jl:678-686)
                 double p = 0.0;
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
                     double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
-                    p = fma(M[L.dq + j * NP + lig], xj, p);
+                    p = fma(Ms[L.dq + j * NP + lig], xj, p);
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    p = fma(M[L.eq + k * NP + lig], ubuf[m * NU + k], p);
+                    p = fma(Ms[L.eq + k * NP + lig], ubuf[m * NU + k], p);
+                });
+                sfor<0, s>([&](auto pc) ACME_LAMBDA {        // earlier sub-problems' z
+                    constexpr int sp = decltype(pc)::value;
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        p = fma(Ms[L.fqprev + (sp * NN + j) * NP + lig], wv::bcast16<j>(zs[sp]), p);
+                    });
                 });
                 if (solve_mode) p = (valid && lig < A.np_io) ? A.p_in[inst * A.np_io + lig] : 0.0;
                 // solve(::HomotopySolver, p) (src/solvers.jl:268-296) as a per-instance
@@ -729,7 +789,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 bool need = alive, conv = false;
                 int mode = 0, its_sample = 0;
                 double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
-                ACME_DBG("sample %lld lane %d p %.17g x %.17g lp %.17g lz %.17g", n, lane, p, x[0], lp, lz);
+                ACME_DBG("sample %lld sub %d lane %d p %.17g x %.17g lp %.17g lz %.17g", n, s, lane, p, x[0], lp, lz);
                 while (wv::ballot(need)) {
                     int its;
                     bool c = base_solve(target, need, its);
@@ -758,30 +818,32 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                         target = sel(need, pa, target);
                     }
                 }
-                zfin = z;
+                zs[s] = alive ? z : 0.0;
                 if (solve_mode) {   // hand the solver's answer back; no y, no state update
                     if (valid && lig < A.nn_io) A.z_out[inst * A.nn_io + lig] = z;
                     if (valid && lig == 0) {
                         A.conv_out[inst] = conv ? 1 : 0;
                         A.iters_out[inst] = its_sample;
                     }
-                    continue;
+                } else {
+                    // convergence policy of step! (src/ACME.jl:688-694)
+                    unsigned long long nf = wv::ballot(lig < NN && !(z * 0.0 == 0.0));
+                    bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+                    bool failed = alive && !conv;
+                    if (wv::ballot(failed)) {
+                        bool warn = failed && zfinite;
+                        bool die = failed && !zfinite;
+                        n_warn += warn ? 1 : 0;
+                        first_nonconv = (warn && first_nonconv < 0) ? n : first_nonconv;
+                        first_nonfinite = (die && first_nonfinite < 0) ? n : first_nonfinite;
+                        dead = dead || die;
+                    }
+                    iters_total += alive ? its_sample : 0;
+                    iters_max = (alive && its_sample > iters_max) ? its_sample : iters_max;
                 }
-                // convergence policy of step! (src/ACME.jl:688-694)
-                unsigned long long nf = wv::ballot(lig < NN && !(z * 0.0 == 0.0));
-                bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
-                bool failed = alive && !conv;
-                if (wv::ballot(failed)) {
-                    bool warn = failed && zfinite;
-                    bool die = failed && !zfinite;
-                    n_warn += warn ? 1 : 0;
-                    first_nonconv = (warn && first_nonconv < 0) ? n : first_nonconv;
-                    first_nonfinite = (die && first_nonfinite < 0) ? n : first_nonfinite;
-                    dead = dead || die;
-                }
-                iters_total += alive ? its_sample : 0;
-                iters_max = (alive && its_sample > iters_max) ? its_sample : iters_max;
-            }
+                if (S::NSUB > 1) leave_sub(sc);
+            });
+            if (solve_mode) continue;
             if (NU > 0 && m == cnt - 1 && n0 + CHUNK < T) fetch_u(n0 + CHUNK);
             const bool live = !dead;
             // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
@@ -795,9 +857,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     constexpr int k = decltype(kc)::value;
                     yy = fma(M[L.ey + k * NY + lig], ubuf[m * NU + k], yy);
                 });
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    yy = fma(M[L.fy + j * NY + lig], wv::bcast16<j>(zfin), yy);
+                sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
+                    constexpr int s = decltype(sc)::value;
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        yy = fma(M[L.fy + (s * NN + j) * NY + lig], wv::bcast16<j>(zs[s]), yy);
+                    });
                 });
                 if (lig < NY) ybuf[m * NY + lig] = live ? yy : (double)NAN;
             }
@@ -824,12 +889,15 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                         xn[s] = fma(M[L.b + k * NX + s * GROUP + lig], uk, xn[s]);
                     });
                 });
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    double zj = wv::bcast16<j>(zfin);
-                    sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
-                        constexpr int s = decltype(sc)::value;
-                        xn[s] = fma(M[L.c + j * NX + s * GROUP + lig], zj, xn[s]);
+                sfor<0, S::NSUB>([&](auto pc) ACME_LAMBDA {
+                    constexpr int sp = decltype(pc)::value;
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        double zj = wv::bcast16<j>(zs[sp]);
+                        sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                            constexpr int s = decltype(sc)::value;
+                            xn[s] = fma(M[L.c + (sp * NN + j) * NX + s * GROUP + lig], zj, xn[s]);
+                        });
                     });
                 });
                 sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
@@ -855,8 +923,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             int i = s * GROUP + lig;
             if (i < NX) st[i] = x[s];
         });
-        if (NP > 0 && lig < NP) st[NX + lig] = lp;
-        if (NN > 0 && lig < NN) st[NX + NP + lig] = lz;
+        if (S::NSUB == 1) leave_sub(std::integral_constant<int, 0>{});
+        sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
+            constexpr int s = decltype(sc)::value;
+            if (NP > 0 && lig < NP) st[NX + s * NP + lig] = lps[s];
+            if (NN > 0 && lig < NN) st[NX + NSUB * NP + s * NN + lig] = lzs[s];
+        });
         if (lig == 0 && !solve_mode) {
             long long *rp = A.report + inst * RW_WORDS;
             rp[RW_NWARN] = n_warn;

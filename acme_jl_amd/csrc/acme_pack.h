@@ -48,7 +48,7 @@ struct Packed {
 
 inline const std::vector<Dims> &shape_list() {
     static const std::vector<Dims> v = {
-#define ACME_X(nn, nq, np, nx, nu, ny, rare) Dims{nn, nq, np, nx, nu, ny, rare},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub) Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -77,15 +77,17 @@ inline bool choose_shape(const Dims &d, Dims &out) {
         long best = -1;
         for (const Dims &s : list) {
             if (d.rare && !s.rare) continue;
+            if (d.nsub > s.nsub) continue;
             if (pass == 0 && s.nn != 0) continue;
-            if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny) {
+            if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny &&
+                s.nsub == d.nsub) {
                 out = s;
                 return true;
             }
             bool fits = d.nn <= s.nn && d.np <= s.np && d.nx <= s.nx && d.nu <= s.nu && d.ny <= s.ny &&
                         d.nq + (s.nn - d.nn) <= s.nq;
             if (!fits) continue;
-            long cost = (long)s.nn * s.nn * s.nn + (long)s.nq * (s.nn + s.np) +
+            long cost = (long)(s.nsub ? s.nsub : 1) * ((long)s.nn * s.nn * s.nn + (long)s.nq * (s.nn + s.np)) +
                         (long)(s.nx + s.np + s.ny) * (s.nx + s.nu + s.nn);
             if (best < 0 || cost < best) {
                 best = cost;
@@ -103,37 +105,150 @@ inline void put(std::vector<double> &img, int off, int ld, const std::vector<dou
         for (int i = 0; i < r; ++i) img[off + (size_t)j * ld + i] = m[(size_t)j * r + i];
 }
 
-inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Dims *force_shape = nullptr) {
-    if (m.subs.size() > 1) {
-        err = "models with more than one nonlinear sub-problem are not supported by the GPU path yet; "
-              "derive the model with decompose_nonlinearity=false";
+// constants, flags and Jq-column table of the residual rows of one element
+inline bool describe_element(int kind, const double *p, int er, int q0_, double *rc /*[ROWC]*/, int *ri /*[ROWI]*/,
+                             Packed &P, std::string &err) {
+    for (int c = 0; c < ROWC; ++c) rc[c] = 0.0;
+    for (int w = 0; w < ROWI; ++w) ri[w] = 0;
+    ri[0] = kind;  // RowKind numbering == element kind numbering
+    ri[1] = er;
+    // q rows the residual row depends on = columns of its Jq non-zeros
+    int tcs[4] = {q0_, q0_, q0_, q0_};
+    int flags = 0;
+    switch (kind) {
+    case EK_DIODE: {  // src/elements.jl:238-244 -- (v, i)
+        double is = p[0], eta = p[1];
+        tcs[1] = q0_ + 1;
+        rc[0] = 1 / (25e-3 * eta);
+        rc[1] = is;
+        rc[2] = is / (25e-3 * eta);
+        break;
+    }
+    case EK_BJT: {  // src/elements.jl:323-401 -- (vE, vC, iE|iC)
+        double ise = p[0], isc = p[1], etae = p[2], etac = p[3], bf = p[4], br = p[5], ile = p[6], ilc = p[7],
+               etael = p[8], etacl = p[9], vaf = p[10], var = p[11], ikf = p[12], ikr = p[13];
+        tcs[1] = q0_ + 1;
+        tcs[2] = q0_ + 2 + er;
+        rc[0] = 1 / (25e-3 * etae);
+        rc[1] = 1 / (25e-3 * etac);
+        rc[2] = bf / (1 + bf) * ise;
+        rc[3] = br / (1 + br) * isc;
+        rc[4] = bf / (1 + bf) * ise / (25e-3 * etae);
+        rc[5] = br / (1 + br) * isc / (25e-3 * etac);
+        rc[6] = 1 / bf;
+        rc[7] = 1 / br;
+        rc[8] = 1 / var;
+        rc[9] = 1 / vaf;
+        rc[10] = 1 / ikf;
+        rc[11] = 1 / ikr;
+        rc[12] = ile;
+        rc[13] = ilc;
+        rc[14] = 1 / (25e-3 * etael);
+        rc[15] = 1 / (25e-3 * etacl);
+        rc[16] = ile / (25e-3 * etae);  // sic: the reference uses eta_e here (:384)
+        rc[17] = ilc / (25e-3 * etac);  // and eta_c here (:395)
+        rc[18] = -1 / var;
+        rc[19] = -1 / vaf;
+        if (!(std::isinf(var) && std::isinf(vaf))) flags |= RF_EARLY;
+        if (!(std::isinf(ikf) && std::isinf(ikr))) flags |= RF_KNEE;
+        if (ile != 0) flags |= RF_ILE;
+        if (ilc != 0) flags |= RF_ILC;
+        if (etael != etae) flags |= RF_ETAEL;
+        if (etacl != etac) flags |= RF_ETACL;
+        P.has_bjt = 1;
+        if (P.nterms < 3) P.nterms = 3;
+        if (flags) P.rare_kinds = 1;  // Gummel-Poon terms live in the RARE build
+        break;
+    }
+    case EK_POT:  // src/elements.jl:25-30 -- (v, i, pos) of this half
+        tcs[0] = q0_ + er;
+        tcs[1] = q0_ + 2 + er;
+        tcs[2] = q0_ + 4;
+        rc[0] = p[0];
+        if (P.nterms < 3) P.nterms = 3;
+        break;
+    case EK_MOSFET: {  // src/elements.jl:444-479
+        tcs[1] = q0_ + 1;
+        tcs[2] = q0_ + 2;
+        for (int c = 0; c < 12; ++c) rc[c] = p[c];
+        int nvt = (int)p[2], na = (int)p[7];
+        for (int k = 1; k < nvt; ++k) rc[12 + k - 1] = p[3 + k] * k;
+        for (int k = 1; k < na; ++k) rc[15 + k - 1] = p[8 + k] * k;
+        P.rare_kinds = 1;
+        if (P.nterms < 3) P.nterms = 3;
+        break;
+    }
+    case EK_MACAK:  // src/elements.jl:540-546
+        tcs[1] = q0_ + 1;
+        rc[0] = p[0];
+        rc[1] = p[1];
+        rc[2] = p[0] / p[1];
+        P.rare_kinds = 1;
+        break;
+    case EK_JA: {  // src/elements.jl:107-129
+        double Ms = p[0], a = p[1], alpha = p[2], c = p[3];
+        tcs[1] = q0_ + 1;
+        tcs[2] = q0_ + 2;
+        tcs[3] = q0_ + 3;
+        for (int k = 0; k < 5; ++k) rc[k] = p[k];
+        rc[5] = 1e-4 / Ms;
+        rc[6] = c * Ms / a;
+        rc[7] = c * Ms / a * alpha;
+        P.rare_kinds = 1;
+        P.nterms = 4;
+        break;
+    }
+    default:
+        err = "unknown element kind";
         return false;
     }
+    ri[2] = flags;
+    for (int t = 0; t < 4; ++t) ri[3 + t] = tcs[t];
+    return true;
+}
+
+inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Dims *force_shape = nullptr) {
     Dims d{};
     d.nx = m.nx; d.nu = m.nu; d.ny = m.ny;
-    const HostSub *s = m.subs.empty() ? nullptr : &m.subs[0];
-    if (s) {
-        d.nn = s->nn; d.nq = s->nq; d.np = s->np;
-        for (size_t e = 0; e < s->kind.size(); ++e) {
-            int kd = s->kind[e];
+    d.nsub = (int)m.subs.size();
+    if (d.nsub > MAX_NSUB) {
+        err = "more than 4 nonlinear sub-problems are not supported by the GPU path; derive the model with "
+              "decompose_nonlinearity=false";
+        return false;
+    }
+    // every sub-problem is padded to the largest one
+    int pad_need = 0;
+    for (const HostSub &s : m.subs) {
+        if (s.nn > d.nn) d.nn = s.nn;
+        if (s.np > d.np) d.np = s.np;
+        for (size_t e = 0; e < s.kind.size(); ++e) {
+            int kd = s.kind[e];
             if (kd == EK_MOSFET || kd == EK_MACAK || kd == EK_JA) d.rare = 1;
             if (kd == EK_BJT) {  // any Gummel-Poon refinement (src/elements.jl:331-396)
-                const double *p = &s->par[e * MAX_ELEM_PAR];
+                const double *p = &s.par[e * MAX_ELEM_PAR];
                 if (p[6] != 0 || p[7] != 0 || !std::isinf(p[10]) || !std::isinf(p[11]) || !std::isinf(p[12]) ||
                     !std::isinf(p[13]))
                     d.rare = 1;
             }
         }
     }
+    for (const HostSub &s : m.subs) {  // q rows incl. the rows the nn-padding of that sub-problem adds
+        int need = s.nq + (d.nn - s.nn);
+        if (need > pad_need) pad_need = need;
+    }
+    d.nq = pad_need;
     if (d.nn > MAX_NN || d.nq > MAX_NQ || d.np > MAX_NP || d.nx > MAX_NX || d.nu > MAX_NU || d.ny > MAX_NY) {
         err = "model dimensions exceed the limits of the 16-lane kernel (nn<=16, nq<=32, np<=16, nx<=32, nu<=8, ny<=16)";
         return false;
     }
     Dims S{};
+    auto fits = [&](const Dims &s_) {
+        return d.nn <= s_.nn && d.np <= s_.np && d.nx <= s_.nx && d.nu <= s_.nu && d.ny <= s_.ny && d.nsub <= s_.nsub &&
+               d.nq + (s_.nn - d.nn) <= s_.nq && (!d.rare || s_.rare);
+    };
     if (force_shape) {
         S = *force_shape;
-        if (!(d.nn <= S.nn && d.np <= S.np && d.nx <= S.nx && d.nu <= S.nu && d.ny <= S.ny &&
-              d.nq + (S.nn - d.nn) <= S.nq && (!d.rare || S.rare))) {
+        if (!fits(S)) {
             err = "model does not fit the batch's kernel shape";
             return false;
         }
@@ -144,7 +259,8 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     P.shape = S;
     P.actual = d;
     const int NT = S.rare ? 4 : 3;
-    const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny, NT);
+    const int NSUBr = S.nsub > 0 ? S.nsub : 1;
+    const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny, NT, NSUBr);
     P.image.assign(L.total, 0.0);
     put(P.image, L.a, S.nx, m.a, d.nx, d.nx);
     put(P.image, L.b, S.nx, m.b, d.nx, d.nu);
@@ -152,155 +268,79 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     put(P.image, L.dy, S.ny, m.dy, d.ny, d.nx);
     put(P.image, L.ey, S.ny, m.ey, d.ny, d.nu);
     put(P.image, L.y0, S.ny, m.y0, d.ny, 1);
-    P.rowc.assign((size_t)ROWC * GROUP, 0.0);
-    P.rowi.assign((size_t)ROWI * GROUP, 0);
-    P.init_state.assign((size_t)S.nx + S.np + S.nn, 0.0);
+    P.rowc.assign((size_t)NSUBr * ROWC * GROUP, 0.0);
+    P.rowi.assign((size_t)NSUBr * ROWI * GROUP, 0);
+    P.init_state.assign((size_t)S.nx + (size_t)NSUBr * (S.np + S.nn), 0.0);
     P.nterms = 2; P.has_bjt = 0; P.rare_kinds = 0;
-    if (s) {
-        put(P.image, L.c, S.nx, m.c, d.nx, d.nn);
-        put(P.image, L.fy, S.ny, m.fy, d.ny, d.nn);
-        put(P.image, L.dq, S.np, s->dq, d.np, d.nx);
-        put(P.image, L.eq, S.np, s->eq, d.np, d.nu);
-        for (int i = 0; i < d.nn; ++i) P.init_state[S.nx + S.np + i] = s->init_z[i];
-        std::vector<int> pos_of(d.nn);
-        for (int i = 0; i < d.nn; ++i) pos_of[i] = i;
+    // actual z offsets of the sub-problems inside the reference's z vector
+    std::vector<int> zoff(m.subs.size() + 1, 0);
+    for (size_t k = 0; k < m.subs.size(); ++k) zoff[k + 1] = zoff[k] + m.subs[k].nn;
+    for (size_t k = 0; k < m.subs.size(); ++k) {
+        const HostSub *s = &m.subs[k];
+        const int base = L.sub0 + (int)k * L.sub_stride;
+        // c and fy: this sub-problem's z columns go to padded columns k*NN ...
+        for (int j = 0; j < s->nn; ++j) {
+            for (int i = 0; i < d.nx; ++i) P.image[L.c + ((size_t)k * S.nn + j) * S.nx + i] = m.c[(size_t)(zoff[k] + j) * d.nx + i];
+            for (int i = 0; i < d.ny; ++i) P.image[L.fy + ((size_t)k * S.nn + j) * S.ny + i] = m.fy[(size_t)(zoff[k] + j) * d.ny + i];
+        }
+        put(P.image, base + L.dq, S.np, s->dq, s->np, d.nx);
+        put(P.image, base + L.eq, S.np, s->eq, s->np, d.nu);
+        for (size_t kp = 0; kp < k; ++kp)  // fqprev: columns of the earlier sub-problems
+            for (int j = 0; j < m.subs[kp].nn; ++j)
+                for (int i = 0; i < s->np; ++i)
+                    P.image[base + L.fqprev + ((size_t)kp * S.nn + j) * S.np + i] = s->fqprev[(size_t)(zoff[kp] + j) * s->np + i];
+        for (int i = 0; i < s->nn; ++i) P.init_state[(size_t)S.nx + (size_t)NSUBr * S.np + k * S.nn + i] = s->init_z[i];
+
+        double *rowc = &P.rowc[k * ROWC * GROUP];
+        int *rowi = &P.rowi[k * ROWI * GROUP];
+        std::vector<int> pos_of(s->nn);
+        for (int i = 0; i < s->nn; ++i) pos_of[i] = i;
         if (!s->row_order.empty()) {
-            if ((int)s->row_order.size() != d.nn) { err = "row_order has the wrong length"; return false; }
-            std::vector<int> seen(d.nn, 0);
-            for (int pos = 0; pos < d.nn; ++pos) {
+            if ((int)s->row_order.size() != s->nn) { err = "row_order has the wrong length"; return false; }
+            std::vector<int> seen(s->nn, 0);
+            for (int pos = 0; pos < s->nn; ++pos) {
                 int r = s->row_order[pos];
-                if (r < 0 || r >= d.nn || seen[r]) { err = "row_order is not a permutation"; return false; }
+                if (r < 0 || r >= s->nn || seen[r]) { err = "row_order is not a permutation"; return false; }
                 seen[r] = 1;
                 pos_of[r] = pos;
             }
         }
-        auto RC = [&](int row, int c) -> double & { return P.rowc[(size_t)c * GROUP + pos_of[row]]; };
-        auto RI = [&](int row, int w) -> int & { return P.rowi[(size_t)w * GROUP + pos_of[row]]; };
         for (size_t e = 0; e < s->kind.size(); ++e) {
             int kind = s->kind[e], knq, knn;
             kind_shape(kind, knq, knn);
-            const double *p = &s->par[e * MAX_ELEM_PAR];
             for (int er = 0; er < knn; ++er) {
                 int row = s->roff[e] + er;
-                if (row >= d.nn) { err = "element table row out of range"; return false; }
-                RI(row, 0) = kind;  // RowKind numbering == element kind numbering
-                RI(row, 1) = er;
-                // q rows the residual row depends on = columns of its Jq non-zeros
-                const int q0_ = s->qoff[e];
-                int tcs[4] = {q0_, q0_, q0_, q0_};
-                switch (kind) {
-                case EK_DIODE: tcs[1] = q0_ + 1; break;                                     // (v, i)
-                case EK_BJT: tcs[1] = q0_ + 1; tcs[2] = q0_ + 2 + er; break;                // (vE, vC, iE|iC)
-                case EK_POT: tcs[0] = q0_ + er; tcs[1] = q0_ + 2 + er; tcs[2] = q0_ + 4; break;  // (v, i, pos)
-                case EK_MOSFET: tcs[1] = q0_ + 1; tcs[2] = q0_ + 2; break;
-                case EK_MACAK: tcs[1] = q0_ + 1; break;
-                case EK_JA: tcs[1] = q0_ + 1; tcs[2] = q0_ + 2; tcs[3] = q0_ + 3; break;
-                default: break;
-                }
-                for (int t = 0; t < 4; ++t) RI(row, 3 + t) = tcs[t];
-                int flags = 0;
-                switch (kind) {
-                case EK_DIODE: {  // src/elements.jl:238-244
-                    double is = p[0], eta = p[1];
-                    RC(row, 0) = 1 / (25e-3 * eta);
-                    RC(row, 1) = is;
-                    RC(row, 2) = is / (25e-3 * eta);
-                    break;
-                }
-                case EK_BJT: {  // src/elements.jl:323-401
-                    double ise = p[0], isc = p[1], etae = p[2], etac = p[3], bf = p[4], br = p[5], ile = p[6],
-                           ilc = p[7], etael = p[8], etacl = p[9], vaf = p[10], var = p[11], ikf = p[12], ikr = p[13];
-                    RC(row, 0) = 1 / (25e-3 * etae);
-                    RC(row, 1) = 1 / (25e-3 * etac);
-                    RC(row, 2) = bf / (1 + bf) * ise;
-                    RC(row, 3) = br / (1 + br) * isc;
-                    RC(row, 4) = bf / (1 + bf) * ise / (25e-3 * etae);
-                    RC(row, 5) = br / (1 + br) * isc / (25e-3 * etac);
-                    RC(row, 6) = 1 / bf;
-                    RC(row, 7) = 1 / br;
-                    RC(row, 8) = 1 / var;
-                    RC(row, 9) = 1 / vaf;
-                    RC(row, 10) = 1 / ikf;
-                    RC(row, 11) = 1 / ikr;
-                    RC(row, 12) = ile;
-                    RC(row, 13) = ilc;
-                    RC(row, 14) = 1 / (25e-3 * etael);
-                    RC(row, 15) = 1 / (25e-3 * etacl);
-                    RC(row, 16) = ile / (25e-3 * etae);  // sic: the reference uses eta_e here (:384)
-                    RC(row, 17) = ilc / (25e-3 * etac);  // and eta_c here (:395)
-                    RC(row, 18) = -1 / var;
-                    RC(row, 19) = -1 / vaf;
-                    if (!(std::isinf(var) && std::isinf(vaf))) flags |= RF_EARLY;
-                    if (!(std::isinf(ikf) && std::isinf(ikr))) flags |= RF_KNEE;
-                    if (ile != 0) flags |= RF_ILE;
-                    if (ilc != 0) flags |= RF_ILC;
-                    if (etael != etae) flags |= RF_ETAEL;
-                    if (etacl != etac) flags |= RF_ETACL;
-                    P.has_bjt = 1;
-                    if (P.nterms < 3) P.nterms = 3;
-                    if (flags & (RF_ILE | RF_ILC)) P.rare_kinds |= 0;  // handled inside the BJT branch
-                    break;
-                }
-                case EK_POT:  // src/elements.jl:25-30
-                    RC(row, 0) = p[0];
-                    if (P.nterms < 3) P.nterms = 3;
-                    break;
-                case EK_MOSFET: {  // src/elements.jl:444-447
-                    for (int c = 0; c < 12; ++c) RC(row, c) = p[c];
-                    int nvt = (int)p[2], na = (int)p[7];
-                    for (int k = 1; k < nvt; ++k) RC(row, 12 + k - 1) = p[3 + k] * k;
-                    for (int k = 1; k < na; ++k) RC(row, 15 + k - 1) = p[8 + k] * k;
-                    P.rare_kinds = 1;
-                    if (P.nterms < 3) P.nterms = 3;
-                    break;
-                }
-                case EK_MACAK:  // src/elements.jl:540-546
-                    RC(row, 0) = p[0];
-                    RC(row, 1) = p[1];
-                    RC(row, 2) = p[0] / p[1];
-                    P.rare_kinds = 1;
-                    break;
-                case EK_JA: {  // src/elements.jl:107-129
-                    double Ms = p[0], a = p[1], alpha = p[2], c = p[3];
-                    for (int k = 0; k < 5; ++k) RC(row, k) = p[k];
-                    RC(row, 5) = 1e-4 / Ms;
-                    RC(row, 6) = c * Ms / a;
-                    RC(row, 7) = c * Ms / a * alpha;
-                    P.rare_kinds = 1;
-                    P.nterms = 4;
-                    break;
-                }
-                default:
-                    err = "unknown element kind";
-                    return false;
-                }
-                RI(row, 2) = flags;
-                if (kind == EK_BJT && flags) P.rare_kinds = 1;  // Gummel-Poon terms live in the RARE build
+                if (row >= s->nn) { err = "element table row out of range"; return false; }
+                double rc[ROWC];
+                int ri[ROWI];
+                if (!describe_element(kind, &s->par[e * MAX_ELEM_PAR], er, s->qoff[e], rc, ri, P, err)) return false;
+                for (int c = 0; c < ROWC; ++c) rowc[(size_t)c * GROUP + pos_of[row]] = rc[c];
+                for (int w = 0; w < ROWI; ++w) rowi[(size_t)w * GROUP + pos_of[row]] = ri[w];
             }
         }
-    }
-    // shape padding: extra unknowns z_pad with the trivial equation q_pad = z_pad = 0
-    std::vector<double> fqp((size_t)S.nq * S.nn, 0.0), pexpp((size_t)S.nq * S.np, 0.0), q0p(S.nq, 0.0);
-    if (s) {
-        put(fqp, 0, S.nq, s->fq, d.nq, d.nn);
-        put(pexpp, 0, S.nq, s->pexp, d.nq, d.np);
-        put(q0p, 0, S.nq, s->q0, d.nq, 1);
-    }
-    for (int r = d.nn; r < S.nn; ++r) {
-        int qrow = d.nq + (r - d.nn);
-        fqp[(size_t)r * S.nq + qrow] = 1.0;
-        P.rowi[0 * GROUP + r] = RK_PAD;
-        for (int t = 0; t < 4; ++t) P.rowi[(3 + t) * GROUP + r] = qrow;
-    }
-    // row-gathered copies of fq / pexp / q0 (see Layout): slot `pos` = the lane position of
-    // the residual row, term t = its t-th Jq non-zero
-    for (int pos = 0; pos < S.nn; ++pos)
-        for (int t = 0; t < NT; ++t) {
-            int tc = P.rowi[(3 + t) * GROUP + pos];
-            for (int j = 0; j < S.nn; ++j) P.image[L.fqr + ((size_t)t * S.nn + j) * GROUP + pos] = fqp[(size_t)j * S.nq + tc];
-            for (int j = 0; j < S.np; ++j) P.image[L.pexpr + ((size_t)t * S.np + j) * GROUP + pos] = pexpp[(size_t)j * S.nq + tc];
-            P.image[L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
+        // shape padding: extra unknowns z_pad with the trivial equation q_pad = z_pad = 0
+        std::vector<double> fqp((size_t)S.nq * S.nn, 0.0), pexpp((size_t)S.nq * S.np, 0.0), q0p(S.nq, 0.0);
+        put(fqp, 0, S.nq, s->fq, s->nq, s->nn);
+        put(pexpp, 0, S.nq, s->pexp, s->nq, s->np);
+        put(q0p, 0, S.nq, s->q0, s->nq, 1);
+        for (int r = s->nn; r < S.nn; ++r) {
+            int qrow = s->nq + (r - s->nn);
+            fqp[(size_t)r * S.nq + qrow] = 1.0;
+            rowi[0 * GROUP + r] = RK_PAD;
+            for (int t = 0; t < 4; ++t) rowi[(3 + t) * GROUP + r] = qrow;
         }
+        // row-gathered copies of fq / pexp / q0 (see Layout): slot `pos` = the lane position of
+        // the residual row, term t = its t-th Jq non-zero
+        for (int pos = 0; pos < S.nn; ++pos)
+            for (int t = 0; t < NT; ++t) {
+                int tc = rowi[(3 + t) * GROUP + pos];
+                for (int j = 0; j < S.nn; ++j)
+                    P.image[base + L.fqr + ((size_t)t * S.nn + j) * GROUP + pos] = fqp[(size_t)j * S.nq + tc];
+                for (int j = 0; j < S.np; ++j)
+                    P.image[base + L.pexpr + ((size_t)t * S.np + j) * GROUP + pos] = pexpp[(size_t)j * S.nq + tc];
+                P.image[base + L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
+            }
+    }
     return true;
 }
 

@@ -1,4 +1,4 @@
-// acme_shapes.h -- the (NN,NQ,NP,NX,NU,NY,RARE) shapes the kernel is instantiated for.
+// acme_shapes.h -- the (NN,NQ,NP,NX,NU,NY,RARE,NSUB) shapes the kernel is instantiated for.
 //
 // Loop bounds, DPP lane selects and register-array subscripts are compile-time constants
 // (the reference gets the same effect from Julia specialising StaticArrays sizes per
@@ -9,13 +9,15 @@
 #pragma once
 // clang-format off
 #define ACME_SHAPES(X)                                                                     \
-    X( 2,  4,  1,  1, 1, 1, 0)  /* examples/diodeclipper.jl                             */ \
-    X( 7, 14,  5, 11, 1, 1, 0)  /* examples/superover.jl, fixed potentiometers          */ \
-    X(13, 29, 11, 11, 4, 1, 0)  /* examples/superover.jl, drive/tone/level as inputs    */ \
-    X( 2,  4,  2,  3, 1, 1, 0)  /* examples/birdie.jl, fixed vol                        */ \
-    X( 4,  9,  3,  3, 2, 1, 0)  /* examples/birdie.jl, vol as input                     */ \
-    X( 0,  0,  0, 32, 2, 2, 0)  /* linear models (no nonlinear sub-problem)             */ \
-    X( 4, 12,  4,  4, 2, 4, 1)  /* generic small  (all element kinds)                   */ \
-    X( 8, 24,  8, 16, 4, 4, 1)  /* generic medium (all element kinds)                   */ \
-    X(16, 32, 16, 32, 8, 8, 1)  /* generic large  (all element kinds)                   */
+    X( 2,  4,  1,  1, 1, 1, 0, 1)  /* examples/diodeclipper.jl                          */ \
+    X( 7, 14,  5, 11, 1, 1, 0, 1)  /* examples/superover.jl, fixed potentiometers       */ \
+    X(13, 29, 11, 11, 4, 1, 0, 1)  /* examples/superover.jl, drive/tone/level as inputs */ \
+    X( 2,  4,  2,  3, 1, 1, 0, 1)  /* examples/birdie.jl, fixed vol                     */ \
+    X( 4,  9,  3,  3, 2, 1, 0, 1)  /* examples/birdie.jl, vol as input                  */ \
+    X( 0,  0,  0, 32, 2, 2, 0, 1)  /* linear models (no nonlinear sub-problem)          */ \
+    X( 4, 12,  4,  4, 2, 4, 1, 1)  /* generic small  (all element kinds)                */ \
+    X( 8, 24,  8, 16, 4, 4, 1, 1)  /* generic medium (all element kinds)                */ \
+    X(16, 32, 16, 32, 8, 8, 1, 1)  /* generic large  (all element kinds)                */ \
+    X( 4, 12,  4, 16, 4, 4, 1, 4)  /* decomposed nonlinearity: up to 4 small sub-problems */ \
+    X( 8, 24,  8, 16, 4, 4, 1, 4)  /* decomposed nonlinearity: up to 4 medium sub-problems */
 // clang-format on

@@ -108,7 +108,7 @@ class Library:
         L.acme_batch_destroy.restype = None
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
-        L.acme_batch_solve.argtypes = [vp, dp, dp, ip, ip, C.c_int, vp]
+        L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.acme_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
         L.acme_batch_get_report.argtypes = [vp, C.POINTER(Report)]
@@ -344,26 +344,25 @@ class ModelRunner:
         """``set_resabstol!`` (src/solvers.jl:181,262)."""
         self.lib.check(self.lib.L.acme_batch_set_resabstol(self.h, float(tol)))
 
-    def solve(self, p):
-        """Batched ``solve(solver, p)`` (src/solvers.jl:207-236, 268-302): ``p`` is (N, np);
-        returns ``(z, hasconverged, needediterations)`` with shapes (N, nn), (N,), (N,).  Uses
-        and updates each instance's extrapolation origin like the reference's solver objects."""
-        s = self.model.subs[0]
+    def solve(self, p, sub=0):
+        """Batched ``solve(model.solvers[sub+1], p)`` (src/solvers.jl:207-236, 268-302): ``p`` is
+        (N, np); returns ``(z, hasconverged, needediterations)`` with shapes (N, nn), (N,), (N,).
+        Uses and updates each instance's extrapolation origin like the reference's solver objects."""
+        s = self.model.subs[sub]
         p = np.ascontiguousarray(np.broadcast_to(np.asarray(p, dtype=np.float64), (self.n, s.np)))
         z = np.zeros((self.n, s.nn))
         conv = np.zeros(self.n, dtype=np.int32)
         iters = np.zeros(self.n, dtype=np.int32)
-        self.lib.check(self.lib.L.acme_batch_solve(self.h, _dp(p), _dp(z), _ip(conv), _ip(iters),
+        self.lib.check(self.lib.L.acme_batch_solve(self.h, int(sub), _dp(p), _dp(z), _ip(conv), _ip(iters),
                                                    ACME_MEM_HOST, None))
         return z, conv.astype(bool), iters
 
     def get_state(self):
         """(x, last_p, last_z): model.x and the extrapolation origin of every instance."""
         m = self.model
-        s = m.subs[0] if m.subs else None
         x = np.zeros((self.n, m.nx))
-        p = np.zeros((self.n, s.np if s else 0))
-        z = np.zeros((self.n, s.nn if s else 0))
+        p = np.zeros((self.n, sum(s.np for s in m.subs)))
+        z = np.zeros((self.n, sum(s.nn for s in m.subs)))
         self.lib.check(self.lib.L.acme_batch_get_state(self.h, _dp(x), _dp(p), _dp(z)))
         return x, p, z
 
@@ -374,10 +373,9 @@ class ModelRunner:
             a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.n, cols)))
             return a, _dp(a)
         m = self.model
-        s = m.subs[0] if m.subs else None
         xa, xp = prep(x, m.nx)
-        pa, pp = prep(p, s.np if s else 0)
-        za, zp = prep(z, s.nn if s else 0)
+        pa, pp = prep(p, sum(s.np for s in m.subs))
+        za, zp = prep(z, sum(s.nn for s in m.subs))
         self.lib.check(self.lib.L.acme_batch_set_state(self.h, xp, pp, zp))
 
     def kernel_shape(self):

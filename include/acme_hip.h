@@ -130,11 +130,11 @@ int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int m
 
 /* The solver plugin contract, batched (src/solvers.jl:207-236, 268-302): for every instance
  *   z = solve(solver, p); converged = hasconverged(solver); iters = needediterations(solver)
- * p is [N][np], z is [N][nn] (sub-problem 0), converged/iters are [N].  Like the reference's
+ * on sub-problem `sub` (0-based): p is [N][np_sub], z is [N][nn_sub], converged/iters are [N].  Like the reference's
  * solver objects the call uses and updates the instance's extrapolation origin; x is not
  * touched and nothing is added to the run reports.  mem/stream as for acme_batch_run. */
-int acme_batch_solve(acme_batch *b, const double *p, double *z, int *converged, int *iters,
-                     int mem, void *stream);
+int acme_batch_solve(acme_batch *b, int sub, const double *p, double *z, int *converged,
+                     int *iters, int mem, void *stream);
 
 /* milliseconds the last acme_batch_run kernel took on the device (HIP events recorded on
  * the launch stream); synchronises with that launch */
@@ -151,7 +151,8 @@ int acme_batch_reset_report(acme_batch *b);
 int acme_batch_set_resabstol(acme_batch *b, double tol);
 
 /* model.x and get/set_extrapolation_origin (src/solvers.jl:183-198) for all instances:
- * x is [N][nx], p is [N][np], z is [N][nn] (sub-problem 0); NULL pointers are skipped */
+ * x is [N][nx], p is [N][sum np_k], z is [N][sum nn_k] (sub-problems concatenated in order);
+ * NULL pointers are skipped */
 int acme_batch_get_state(acme_batch *b, double *x, double *p, double *z);
 int acme_batch_set_state(acme_batch *b, const double *x, const double *p, const double *z);
 

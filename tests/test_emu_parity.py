@@ -198,3 +198,43 @@ def test_emulated_steadystate_per_instance_inputs(emu_lib):
     r.run(np.repeat(U[:, :, None], 1, axis=2))
     x, _, _ = r.get_state()
     np.testing.assert_allclose(x, X, rtol=1.5e-8, atol=1e-14)
+
+
+def _simplified_superover(var):
+    """test/runtests.jl:751-756 / :782-787: superover with vb forced by an ideal source ->
+    the nonlinearity decomposes into 3 (fixed pots) / 4 (pots as inputs) sub-problems."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.circuit import voltagesource
+    from acme_jl_amd.model import DiscreteModel
+    c = examples.superover() if var else examples.superover(1.0, 1.0, 1.0)
+    c.add("vbsrc", voltagesource(4.5))
+    c.connect(("vbsrc", "+"), "vb")
+    c.connect(("vbsrc", "-"), "gnd")
+    return DiscreteModel(c, Fraction(1 / 44100))
+
+
+def test_emulated_decomposed_nonlinearity(emu_lib):
+    """Several sub-problems solved one after another each sample, later ones fed by the
+    earlier ones through fqprev (src/ACME.jl:675-697)."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    m = _simplified_superover(False)
+    assert [s.np for s in m.subs] == [2, 1, 2]
+    u = sweep_inputs("superover_fixed", 5, 160)
+    r = emu_runner(emu_lib, m, 5)
+    assert r.kernel_shape()[:3] == (4, 12, 4)
+    yref, its = oracle_run(m, u)
+    assert_close(r.run(u), yref)
+    assert r.report_arrays()["iters_total"].tolist() == its.tolist()
+    x, p, z = r.get_state()
+    assert p.shape == (5, 5) and z.shape == (5, 7)
+    mv = _simplified_superover(True)
+    assert [s.np for s in mv.subs] == [2, 2, 2, 4]
+    uv = sweep_inputs("superover_var", 3, 100)
+    yref, _ = oracle_run(mv, uv)
+    assert_close(emu_runner(emu_lib, mv, 3).run(uv), yref)
+    ms = DiscreteModel(circuits.series_diodes_circuit(), Fraction(1))    # test/runtests.jl:286-291
+    y = emu_runner(emu_lib, ms, 1).run(np.array([[2.0], [1.0]]))
+    np.testing.assert_allclose(y[:, 0], 1e-12 * (np.exp(1 / 25e-3) - 1), rtol=1.5e-8)

@@ -236,3 +236,17 @@ def test_checksteady(hip_lib):
         r.run(np.zeros((3, m.nu, 1)))
         x, _, _ = r.get_state()
         np.testing.assert_allclose(x, xs, rtol=1.5e-8, atol=1e-14)
+
+
+def test_decomposed_nonlinearity(hip_lib):
+    """3 / 4 sub-problems per sample (simplified superover, test/runtests.jl:751-759,782-791)."""
+    from test_emu_parity import _simplified_superover
+    m = _simplified_superover(False)
+    u = sweep_inputs("superover_fixed", 20, 1000)
+    r = runner(hip_lib, m, 20)
+    yref, its = oracle_run(m, u)
+    assert_close(r.run(u), yref)
+    mv = _simplified_superover(True)
+    uv = sweep_inputs("superover_var", 9, 600)
+    yref, _ = oracle_run(mv, uv)
+    assert_close(runner(hip_lib, mv, 9).run(uv), yref)
