@@ -673,6 +673,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 adopt();
             }
             bool small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+            ACME_DBG("emu newton lane %d it %d act %d finite %d res %g z %.17g", lane, its, (int)act, (int)finite, res, z);
 #ifdef ACME_PROFILE_PIECES  // repeat single pieces in situ (results unchanged) to time them
             for (int r_ = 0; r_ < A.prof[1]; ++r_) {
                 double a2[NNr];
@@ -793,6 +794,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 while (wv::ballot(need)) {
                     int its;
                     bool c = base_solve(target, need, its);
+                    ACME_DBG("hom step lane %d need %d mode %d ha %.17g hbest %.17g conv %d its %d", lane, (int)need, mode, ha, hbest, (int)c, its);
                     its_sample += need ? its : 0;
                     conv = need ? c : conv;
                     if (A.solver == SOLVER_SIMPLE) {

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 #define MAXPAR ACME_REF_MAX_PAR
 
@@ -466,6 +467,7 @@ static const double *simple_solve(ref_solver *s, const double *p) {
             if (v > m) m = v;
         }
         s->resmaxabs = nanres ? NAN : m;
+        if (getenv("ACME_REF_TRACE") && atoi(getenv("ACME_REF_TRACE")) > 1) fprintf(stderr, "ref newton it %d resmax %g z0 %.17g\n", s->iters, s->resmaxabs, s->z[0]);
         int finite = isfinite(s->resmaxabs);
         if (finite)
             for (int i = 0; i < nn * nn; ++i)
@@ -528,6 +530,7 @@ static const double *homotopy_solve(ref_solver *s, int kind, const double *p) {
     int np = s->sub->np;
     const double *z = base_solve(s, kind, p);
     s->h_iters = s->iters;
+    if (getenv("ACME_REF_TRACE")) fprintf(stderr, "ref direct conv=%d its=%d resmax=%g\n", simple_hasconverged(s), s->iters, s->resmaxabs);
     if (!simple_hasconverged(s)) {
         double a = 0.5, best_a = 0.0;
         memcpy(s->start_p, s->last_p, sizeof(double) * (size_t)np);
@@ -537,6 +540,7 @@ static const double *homotopy_solve(ref_solver *s, int kind, const double *p) {
             for (int i = 0; i < np; ++i) s->pa[i] += a * p[i];
             z = base_solve(s, kind, s->pa);
             s->h_iters += s->iters;
+            if (getenv("ACME_REF_TRACE")) fprintf(stderr, "ref homotopy a=%.17g best=%.17g conv=%d its=%d resmax=%g\n", a, best_a, simple_hasconverged(s), s->iters, s->resmaxabs);
             if (simple_hasconverged(s)) {
                 best_a = a;
                 a = 1.0;

@@ -121,17 +121,20 @@ def test_emulated_tight_tolerance_parity(emu_lib):
 
 def test_emulated_solver_plugin_contract(emu_lib):
     """solve / hasconverged / needediterations / extrapolation origin (src/solvers.jl:183-236,
-    268-302) through acme_batch_solve, against the oracle's solver object."""
+    268-302) through acme_batch_solve, against the oracle's solver object, on solver inputs
+    taken from real trajectories (random far-from-physical p make the Jacobian's condition
+    number ~1e290: both Newton paths are then numerical noise)."""
     from oracle.refpy import RefRunner
+    from test_gpu_parity import trajectory_ps
     rng = np.random.default_rng(3)
-    for name in ("diodeclipper", "birdie_var"):
+    for name in ("diodeclipper", "superover_fixed", "birdie_var"):
         m = load(name)
-        s = m.subs[0]
-        N = 6
+        ps = trajectory_ps(m, sweep_inputs(name, 2, 140)[1])
+        N = len(ps)
         r = emu_runner(emu_lib, m, N)
         refs = [RefRunner(m) for _ in range(N)]
-        for step in range(4):   # consecutive solves: the origin carries over
-            p = rng.normal(scale=0.3, size=(N, s.np))
+        for step in range(3):   # consecutive solves: the origin carries over
+            p = ps[rng.permutation(N)]
             z, conv, its = r.solve(p)
             for i in range(N):
                 zr, cr, ir = refs[i].solve(p[i])
@@ -145,7 +148,7 @@ def test_emulated_solver_plugin_contract(emu_lib):
         for i in range(N):
             pr, zr = refs[i].get_origin(0)
             np.testing.assert_allclose(lp[i], pr, rtol=1e-12, atol=1e-15)
-            np.testing.assert_allclose(lz[i], zr, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(lz[i], zr, rtol=1e-7, atol=1e-10)
         assert not x.any()      # solve() never touches the state vector
 
 

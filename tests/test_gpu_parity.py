@@ -203,25 +203,39 @@ def test_full_size_properties(hip_lib):
     assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
 
 
+def trajectory_ps(m, u, every=7):
+    """p = dq*x + eq*u along an oracle run: physically reachable solver inputs."""
+    from oracle.refpy import RefRunner
+    r = RefRunner(m)
+    s = m.subs[0]
+    ps = []
+    for n in range(u.shape[1]):
+        if n % every == 0:
+            ps.append(s.dq @ r.x + s.eq @ u[:, n])
+        r.run(u[:, n:n + 1])
+    return np.array(ps)
+
+
 def test_solver_plugin_contract(hip_lib):
     """acme_batch_solve vs the oracle's solver object (solve/hasconverged/needediterations,
-    extrapolation origin; src/solvers.jl:183-236, 268-302)."""
+    extrapolation origin; src/solvers.jl:183-236, 268-302) on solver inputs taken from real
+    trajectories, visited in a shuffled order so that consecutive solves are far apart."""
     from oracle.refpy import RefRunner
     rng = np.random.default_rng(3)
-    for name in ("diodeclipper", "superover_fixed"):
+    for name in ("diodeclipper", "superover_fixed", "birdie_fixed"):
         m = load(name)
-        s = m.subs[0]
-        N = 40
+        ps = trajectory_ps(m, sweep_inputs(name, 2, 420)[1])
+        N = len(ps)
         r = runner(hip_lib, m, N)
         refs = [RefRunner(m) for _ in range(N)]
         for step in range(3):
-            p = rng.normal(scale=0.05, size=(N, s.np))
+            p = ps[rng.permutation(N)]
             z, conv, its = r.solve(p)
             for i in range(N):
                 zr, cr, ir = refs[i].solve(p[i])
-                assert conv[i] == cr
+                assert conv[i] == cr, (name, step, i)
                 if ir <= 20:
-                    assert its[i] == ir
+                    assert its[i] == ir, (name, step, i, its[i], ir)
                 np.testing.assert_allclose(z[i], zr, rtol=1e-7, atol=1e-10)
 
 
