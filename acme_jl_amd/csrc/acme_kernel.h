@@ -55,12 +55,12 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int SCRATCH = (UBUF + YBUF + 2) & ~1;
     // persistent state per instance: x | last_p of every sub-problem | last_z of every sub-problem
     static constexpr int STATE = NX + NSUBr * (NP + NN);
-    // per-wave store of the extrapolation origin's LU factors and Jp: one slab per matrix
+    // per-wave store of the extrapolation origin's  J^-1 * Jp  (nn x np): one slab per matrix
     // column holding the NN rows of each of the wave's 4 instances back to back (lane r keeps
     // row r: consecutive addresses, conflict-free ds_read/write_b64).  LDS per block decides
     // whether 2 blocks (= 2 waves/SIMD) fit a CU, so the slabs are packed to NN rows, not 16.
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
-    static constexpr int ORIGIN1 = (NN + NP) * OSTRIDE;       // one sub-problem
+    static constexpr int ORIGIN1 = NP * OSTRIDE;              // one sub-problem: J^-1 * Jp
     static constexpr int ORIGIN = NSUBr * ORIGIN1 + GROUP;
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
         return (per_instance ? INST_PER_BLOCK : 1) * L.total + NSUBr * (ROWC * GROUP + ROWI * GROUP) +
@@ -127,15 +127,22 @@ ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 // LinearSolver, row-per-lane (src/solvers.jl:46-132).  a[j] = element (lig, j).
 // ---------------------------------------------------------------------------------------
 template <int NN> struct RowLU {
-    // Speculative setlhs!: the same elimination WITHOUT looking for a pivot -- valid whenever
-    // the rows already sit in pivot order, which is the normal case because lanes adopt the
-    // pivot order of the previous factorisation (see wave_main).  Branch-free; returns a wave
-    // mask of the lanes that would have been a strictly larger pivot candidate (or saw a zero
-    // pivot): if the calling instance's bits are non-zero the result is discarded and
-    // factor() below redoes the job with full partial pivoting.
-    template <bool AUG>
-    static ACME_DEV unsigned long long factor_inplace(double (&a)[NN > 0 ? NN : 1], double &b) {
+    // Gauss-Jordan elimination of [A | b | C] in the CURRENT row order, without looking for
+    // pivots -- valid whenever the rows already sit in pivot order, which is the normal case
+    // because lanes adopt the pivot order of the last factorisation that had to interchange
+    // rows (see wave_main).  Row-per-lane makes eliminating above the pivot free (all lanes
+    // execute the same FMA anyway), so there is no back-substitution: on return b = A^-1 b
+    // (component k in lane k) and c[] = A^-1 C.  Same pivots and multipliers as the
+    // reference's setlhs!/solve! (src/solvers.jl:46-132); the upper triangle is eliminated in
+    // a different order, i.e. results agree to rounding.  Branch-free; returns a wave mask of
+    // the lanes that would have been a strictly larger pivot candidate (or saw a zero pivot):
+    // if the calling instance's bits are set the result is discarded and the caller redoes the
+    // job after a partially pivoted factorisation (factor) has told it the pivot order.
+    template <int NC>
+    static ACME_DEV unsigned long long solve_inplace(double (&a)[NN > 0 ? NN : 1], double &b,
+                                                     double (&c)[NC > 0 ? NC : 1]) {
         unsigned long long viol = 0;
+        double dinv = 1.0;   // reciprocal of this lane's pivot
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
             double piv = wv::bcast16<k>(a[k]);
@@ -144,24 +151,37 @@ template <int NN> struct RowLU {
             viol |= (wv::ballot(fabs(a[k]) > fabs(piv)) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))) |
                     wv::ballot(piv == 0.0);
             double inv = wv::recip(piv);
-            double lm = lig_gt<k>() ? a[k] * inv : 0.0;   // multipliers l_ik, 0 on rows <= k
-            double dk = lig_eq<k>() ? inv : a[k];          // reciprocal pivot on the diagonal
-            a[k] = lig_gt<k>() ? lm : dk;
-            // all broadcasts of pivot row k first, then the rank-1 update
-            double bk[NN > 0 ? NN : 1];
-            double bb = 0.0;
-            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                bk[j] = wv::bcast16<k>(a[j]);
-            });
-            if (AUG) bb = wv::bcast16<k>(b);
-            wv::sched_fence();
-            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                a[j] = fma(-lm, bk[j], a[j]);
-            });
-            if (AUG) b = fma(-lm, bb, b);
+            double lm = lig_eq<k>() ? 0.0 : a[k] * inv;    // multipliers of every other row
+            dinv = lig_eq<k>() ? inv : dinv;
+            // broadcasts of pivot row k in batches ahead of the FMAs that consume them (a
+            // dependent dpp->fma pair costs ~17 cycles, a batched one ~9); two batches keep
+            // the number of live temporaries at max(NN, NC + 1)
+            {
+                double bk[NN > 0 ? NN : 1];
+                sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    bk[j] = wv::bcast16<k>(a[j]);
+                });
+                wv::sched_fence();
+                sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    a[j] = fma(-lm, bk[j], a[j]);
+                });
+            }
+            {
+                double bc[NC > 0 ? NC : 1];
+                double bb = wv::bcast16<k>(b);
+                sfor<0, NC>([&](auto jc) ACME_LAMBDA { bc[decltype(jc)::value] = wv::bcast16<k>(c[decltype(jc)::value]); });
+                if (NC > 0) wv::sched_fence();
+                b = fma(-lm, bb, b);
+                sfor<0, NC>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    c[j] = fma(-lm, bc[j], c[j]);
+                });
+            }
         });
+        b *= dinv;
+        sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
         return viol;
     }
 
@@ -212,31 +232,6 @@ template <int NN> struct RowLU {
         return ok;
     }
 
-    // upper-triangular half of solve! (reciprocal diagonal), t = L^-1 P b on entry
-    template <class Acc> static ACME_DEV double back(Acc &&a, double t, int lig) {
-        sfor_down<NN>([&](auto jc) ACME_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            double aj = a(jc);
-            t = lig_eq<j>() ? aj * t : t;
-            double xj = wv::bcast16<j>(t);
-            double um = lig_lt<j>() ? aj : 0.0;
-            t = fma(-um, xj, t);
-        });
-        return t;
-    }
-
-    // solve!: b is distributed one element per lane; returns x likewise.  `a(jc)` yields
-    // element (lig, j) of the factors (registers for the current J, LDS for the origin's).
-    template <class Acc> static ACME_DEV double solve(Acc &&a, double b, int lig) {
-        double t = b;   // stored factors carry no interchanges (lanes adopt the pivot order)
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA {                // unit lower triangle
-            constexpr int j = decltype(jc)::value;
-            double xj = wv::bcast16<j>(t);
-            double lm = lig_gt<j>() ? a(jc) : 0.0;
-            t = fma(-lm, xj, t);
-        });
-        return back(a, t, lig);
-    }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -424,10 +419,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     int *lds_rowi = (int *)(lds_rowc + NSUB * ROWC * GROUP);                       // [NSUB][ROWI*16]
     double *lds_scr = lds_rowc + NSUB * (ROWC * GROUP + ROWI * GROUP);
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
-    double *const olu0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;
+    double *const ojp0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;
     // context of the sub-problem being solved (switched by enter_sub)
-    double *olu = olu0;            // origin factors  [j * OS]
-    double *ojp = olu0 + NN * OS;  // origin Jp       [j * OS]
+    double *ojp = ojp0;            // origin's J^-1 * Jp, row lig: [j * OS]
     const double *rowc_s = lds_rowc;
     const int *rowi_s = lds_rowi;
     {   // cooperative load of the model image(s) and the row tables
@@ -476,9 +470,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double x[NXSr];      // state vector, element s*16+lig
     double lp = 0.0;     // extrapolation origin: last_p[lig]
     double lz = 0.0;     //                       last_z[lig]
-    // last_linsolver's factors and last_Jp live in LDS (olu[j*64], ojp[j*64]), stored in
-    // the lane order in force when they were computed (an LU without internal interchanges
-    // in that order, see adopt()).
+    // the origin's  -dz/dp = last_J^-1 * last_Jp  lives in LDS (ojp[j*OS], row lig): it is all
+    // the first-order extrapolated start (src/solvers.jl:209-215) needs
     double z = 0.0;      // current iterate z[lig]
     double pf[NT];       // (q0 + pexp*p) at the q rows rd.tc[] of this lane's residual row
     // per-row results of the latest evaluate!
@@ -593,14 +586,50 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         load_rowdesc();
     };
 
+    // Solve J dz = res for the J / res of the latest evaluate!(z) (left in a[] / res) by
+    // in-place Gauss-Jordan; with `with_jp` the columns of Jp ride along and the lanes flagged
+    // `store` write their row of J^-1*Jp to the origin slab (set_extrapolation_origin,
+    // src/solvers.jl:191-196).  If the in-place pivots were not the maxima (~4-8 % of calls)
+    // a partially pivoted LU of a fresh J supplies the pivot order, the lanes adopt it and the
+    // elimination is repeated in the new order.  Returns false for a singular J.
+    auto eliminate = [&](bool with_jp, double &dz, bool store = true) ACME_LAMBDA -> bool {
+        bool ok = true;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            unsigned long long viol;
+            double jp[NPr];
+            dz = res;
+            if (with_jp) {
+                calc_jp(jp);
+                viol = LU::template solve_inplace<NP>(a, dz, jp);
+            } else {
+                double none[1] = {0.0};
+                viol = LU::template solve_inplace<0>(a, dz, none);
+            }
+            const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
+            if (attempt == 1) ok = ok && !mine;
+            if (viol == 0ull || attempt == 1) {
+                if (with_jp && store && !mine && lig < NN)   // per-lane predicated LDS stores
+                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
+                break;
+            }
+            // pivot order changed (or J is singular): find it with the reference's partially
+            // pivoted LU on a fresh J, adopt it, evaluate again in the new order
+            (void)evaluate(z);
+            double dummy = 0.0;
+            ok = LU::template factor<false>(a, orig, lig, grp, dummy);
+            adopt();
+            (void)evaluate(z);
+        }
+        return ok;
+    };
+
     // switch the live solver context to sub-problem s / save it back
     auto enter_sub = [&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         Ms = M + L.sub0 + s * L.sub_stride;
         rowc_s = lds_rowc + s * ROWC * GROUP;
         rowi_s = lds_rowi + s * ROWI * GROUP;
-        olu = olu0 + s * S::ORIGIN1;
-        ojp = olu + NN * OS;
+        ojp = ojp0 + s * S::ORIGIN1;
         lp = lps[s];
         lz = lzs[s];
         rowid = rowids[s];
@@ -620,17 +649,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         if (NN > 0 && s < nsub) {
             enter_sub(sc);
             set_p(lp);
-            evaluate(lz);
-            double dummy = 0.0;
-            LU::template factor<false>(a, orig, lig, grp, dummy);
-            adopt();
-            double jp0[NPr];
-            calc_jp(jp0);
-            if (lig < NN) {
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * OS] = a[decltype(jc)::value]; });
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp0[decltype(jc)::value]; });
-            }
             z = lz;
+            (void)evaluate(z);
+            double fwd0;
+            (void)eliminate(true, fwd0);
             leave_sub(sc);
         }
     });
@@ -640,66 +662,36 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // returns hasconverged, leaves needediterations in `its`.
     auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
         set_p(target);
-        // z <- last_z - last_J \ (last_Jp * (p - last_p))
+        // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215)
         double dp = target - lp;
         double t = 0.0;
         sfor<0, NP>([&](auto jc) ACME_LAMBDA {
             constexpr int j = decltype(jc)::value;
             t = fma(ojp[j * OS], wv::bcast16<j>(dp), t);
         });
-        t = LU::solve([&](auto jc) ACME_LAMBDA { return olu[decltype(jc)::value * OS]; }, t, lig);
         z = sel(need, lz - t, z);
         bool act = need, conv = false;
         its = 0;
         while (wv::ballot(act)) {
             its = act ? its + 1 : its;
-#ifdef ACME_PROFILE_PIECES
-            for (int r_ = 0; r_ < A.prof[0]; ++r_) { (void)evaluate(z + 1e-30 * r_); prof_sink += res + a[0]; }
-#endif
             bool finite = evaluate(z);
             // hasconverged (resmaxabs < tol, src/solvers.jl:203): only the boolean is needed, so
             // no max-reduction -- one compare and a ballot; a NaN residual counts as not small
             const unsigned long long big = wv::ballot(!(fabs(res) < A.tol)) & rows4((1ull << NN) - 1ull);
-            // LU before the convergence test (:223-226); res rides along as an augmented
-            // column, so `fwd` = L^-1 P res when the factorisation is done.  First try the
-            // branch-free in-place elimination; only if some instance of this wave needed a
-            // different pivot order (~4 % of factorisations) redo with partial pivoting.
-            double fwd = res;
-            bool ok = true;
-            if (LU::template factor_inplace<true>(a, fwd)) {
-                (void)evaluate(z);
-                fwd = res;
-                ok = LU::template factor<true>(a, orig, lig, grp, fwd);
-                adopt();
-            }
-            bool small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+            const bool small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+            // this iterate becomes the new extrapolation origin if it is accepted
+            const bool want = act && finite && small;
+            // setlhs! comes before the convergence test (:223-226): a singular J ends the solve
+            double dz;
+            const bool ok = eliminate(wv::ballot(want) != 0ull, dz, want);
             ACME_DBG("emu newton lane %d it %d act %d finite %d res %g z %.17g", lane, its, (int)act, (int)finite, res, z);
-#ifdef ACME_PROFILE_PIECES  // repeat single pieces in situ (results unchanged) to time them
-            for (int r_ = 0; r_ < A.prof[1]; ++r_) {
-                double a2[NNr];
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a2[decltype(jc)::value] = a[decltype(jc)::value] + (double)r_; });
-                double f2 = res;
-                prof_sink += (double)(LU::template factor_inplace<true>(a2, f2) & 1ull) + f2 + a2[NN - 1];
-            }
-            for (int r_ = 0; r_ < A.prof[2]; ++r_)
-                prof_sink += LU::back([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, fwd + r_, lig);
-#endif
             bool stop_bad = act && (!finite || !ok);
-            bool stop_conv = act && finite && ok && small;
+            bool stop_conv = want && ok;
             // hasconverged is evaluated on resmaxabs even after a singular-J return
             conv = stop_bad ? (finite && small) : (stop_conv ? true : conv);
-            if (wv::ballot(stop_conv)) {  // refresh the extrapolation origin (:231-234)
-                double jp[NPr];
-                calc_jp(jp);
-                if (stop_conv && lig < NN) {  // per-lane predicated LDS stores, no cross-lane ops inside
-                    sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[decltype(jc)::value * OS] = a[decltype(jc)::value]; });
-                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
-                }
-                lz = sel(stop_conv, z, lz);
-                lp = sel(stop_conv, target, lp);
-            }
+            lz = sel(stop_conv, z, lz);
+            lp = sel(stop_conv, target, lp);
             bool step = act && !stop_bad && !stop_conv;
-            double dz = LU::back([&](auto jc) ACME_LAMBDA { return a[decltype(jc)::value]; }, fwd, lig);
             z = sel(step, z - dz, z);
             act = step && (its < A.maxiter);
         }

@@ -44,6 +44,8 @@ def grid_inputs(workload, rank, world, n_per_gpu, T):
     idx = np.arange(n_per_gpu) + rank * n_per_gpu
     total = n_per_gpu * world
     if workload == "superover_grid":
+        if total % 256:
+            raise SystemExit("superover_grid needs a multiple of 256 instances (16 tone x 16 level per drive value)")
         nd = total // 256
         level = (idx % 16) / 15.0
         tone = ((idx // 16) % 16) / 15.0
