@@ -21,7 +21,14 @@ constexpr int GROUPS_PER_WAVE = 4;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int INST_PER_BLOCK = GROUPS_PER_WAVE * WAVES_PER_BLOCK;
 constexpr int CHUNK = 16;         // samples staged per coalesced u/y transfer
-constexpr int ROWC = 24;          // precomputed constants per residual row
+constexpr int ROWC = 38;          // precomputed constants per residual row
+// rows of the common kinds (diode, Ebers-Moll BJT, potentiometer, padding) in the branch-free
+// "unified row" form the non-RARE kernels evaluate (acme_kernel.h eval_row_unified):
+//   xA = sA*e0, xB = sB*e1, w = w0 + w1*e2
+//   res = cA*(exp(xA)-1) + cB*(exp(xB)-1) + g0*e0 + g1*e1 + g2*e2 + h*w*e1
+//   dres/de0 = dA*exp(xA) + g0,  dres/de1 = dB*exp(xB) + g1 + h*w,  dres/de2 = g2 + h*e1
+enum UnifiedRowConst { UR_SA = 24, UR_SB, UR_CA, UR_CB, UR_DA, UR_DB, UR_H, UR_SPARE,
+                       UR_G0 = 32, UR_G1, UR_G2, UR_W0, UR_W1 };
 constexpr int ROWI = 8;           // ints per residual row: kind, erow, flags, tc[0..3], (spare)
 constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8, MAX_NSUB = 4;
 

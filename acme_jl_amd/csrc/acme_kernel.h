@@ -50,9 +50,9 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
     static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY, RARE_ != 0 ? 4 : 3, NSUBr);
-    // per-instance LDS scratch (doubles): u tile | y tile
-    static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY;
-    static constexpr int SCRATCH = (UBUF + YBUF + 2) & ~1;
+    // per-instance LDS scratch (doubles): u tile | y tile | report words (int64)
+    static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY, RBUF = 6;
+    static constexpr int SCRATCH = (UBUF + YBUF + RBUF + 2) & ~1;
     // persistent state per instance: x | last_p of every sub-problem | last_z of every sub-problem
     static constexpr int STATE = NX + NSUBr * (NP + NN);
     // per-wave store of the extrapolation origin's  J^-1 * Jp  (nn x np): one slab per matrix
@@ -94,6 +94,13 @@ template <int K, int N> ACME_DEV bool lig_in() {                                
 
 ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 
+// pairwise sum of v[I..I+N-1] (depth log2 N instead of a chain of N dependent adds)
+template <int I, int N, int M> ACME_DEV double tree_sum(const double (&v)[M]) {
+    if constexpr (N <= 0) return 0.0;
+    else if constexpr (N == 1) return v[I];
+    else return tree_sum<I, N / 2>(v) + tree_sum<I + N / 2, N - N / 2>(v);
+}
+
 // exp(x) for the junction laws: k = rint(x*log2(e)), r = x - k*ln2 (two-part Cody-Waite),
 // degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18 relative), scale by 2^k with
 // ldexp (which also saturates to inf / flushes to 0 for out-of-range arguments).  About 1 ulp,
@@ -101,20 +108,20 @@ ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 // library routine.  exp(+-inf) gives NaN here (the library gives inf / 0): both make the residual
 // non-finite only in states the solver has already lost.
 ACME_DEV double exp_junction(double x) {
-    const double k = rint(x * 1.4426950408889634);
-    double r = fma(-k, 6.93147180369123816490e-01, x);
-    r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;        // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);      // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);     // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);     // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);    // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);      // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);     // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);     // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);     // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);    // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);    // 1/3!
+    using wv::sconst;
+    const double k = rint(x * sconst(1.4426950408889634));
+    double r = fma(-k, sconst(6.93147180369123816490e-01), x);
+    r = fma(-k, sconst(1.90821492927058770002e-10), r);
+    double p = fma(r, sconst(1.6059043836821613e-10), sconst(2.08767569878681e-09));   // 1/13!, 1/12!
+    p = fma(p, r, sconst(2.505210838544172e-08));     // 1/11!
+    p = fma(p, r, sconst(2.755731922398589e-07));     // 1/10!
+    p = fma(p, r, sconst(2.7557319223985893e-06));    // 1/9!
+    p = fma(p, r, sconst(2.48015873015873e-05));      // 1/8!
+    p = fma(p, r, sconst(1.984126984126984e-04));     // 1/7!
+    p = fma(p, r, sconst(1.388888888888889e-03));     // 1/6!
+    p = fma(p, r, sconst(8.333333333333333e-03));     // 1/5!
+    p = fma(p, r, sconst(4.1666666666666664e-02));    // 1/4!
+    p = fma(p, r, sconst(1.6666666666666666e-01));    // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -135,7 +142,7 @@ template <int NN> struct RowLU {
     // (component k in lane k) and c[] = A^-1 C.  Same pivots and multipliers as the
     // reference's setlhs!/solve! (src/solvers.jl:46-132); the upper triangle is eliminated in
     // a different order, i.e. results agree to rounding.  Branch-free; returns a wave mask of
-    // the lanes that would have been a strictly larger pivot candidate (or saw a zero pivot):
+    // the lanes that would have been a strictly larger pivot candidate (or got a non-finite result):
     // if the calling instance's bits are set the result is discarded and the caller redoes the
     // job after a partially pivoted factorisation (factor) has told it the pivot order.
     template <int NC>
@@ -146,10 +153,8 @@ template <int NN> struct RowLU {
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
             double piv = wv::bcast16<k>(a[k]);
-            // scalar mask arithmetic only: rows k+1..NN-1 with a strictly larger candidate, or
-            // a zero pivot (every lane of the instance sees the same piv)
-            viol |= (wv::ballot(fabs(a[k]) > fabs(piv)) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))) |
-                    wv::ballot(piv == 0.0);
+            // scalar mask arithmetic only: rows k+1..NN-1 with a strictly larger candidate
+            viol = wv::pin(viol | (wv::ballot(fabs(a[k]) > fabs(piv)) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
             double inv = wv::recip(piv);
             double lm = lig_eq<k>() ? 0.0 : a[k] * inv;    // multipliers of every other row
             dinv = lig_eq<k>() ? inv : dinv;
@@ -182,52 +187,40 @@ template <int NN> struct RowLU {
         });
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
+        // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
+        viol |= wv::ballot(!(b * 0.0 == 0.0));
         return viol;
     }
 
-    // setlhs!: in-place LU with partial pivoting (first strict max), reciprocal pivots on
-    // the diagonal.  `orig` returns the original row now stored in this lane (the composed
-    // row interchanges).  Returns false for an exactly singular matrix.
-    // AUG: `b` is carried along as an extra column, i.e. the unit-lower-triangular forward
-    // substitution of solve! (same operations, same order) happens during the elimination.
-    template <bool AUG>
-    static ACME_DEV bool factor(double (&a)[NN > 0 ? NN : 1], int &orig, int lig, int grp, double &b) {
+    // setlhs! with partial pivoting (first strict maximum, src/solvers.jl:58-78), run only to
+    // LEARN the pivot order when solve_inplace reported a violation (a few % of the solves):
+    // `orig` returns the original row now stored in this lane (the composed row interchanges);
+    // the factors are not kept -- the trailing sub-matrix is all the next pivot search needs.
+    // Straight-line code (always search, always interchange).  Returns false for an exactly
+    // singular matrix.
+    static ACME_DEV bool pivot_order(double (&a)[NN > 0 ? NN : 1], int &orig, int lig, int grp) {
         bool ok = true;
         orig = lig;
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
-            // fast path: the in-place candidate already is the first maximum unless some
-            // later row is strictly larger (the usual case with a tuned row order).  Its
-            // reciprocal is started speculatively so that the rcp/Newton chain overlaps the
-            // tail of the previous step's rank-1 update instead of waiting behind the test.
+            double v = lig_in<k, NN>() ? fabs(a[k]) : -1.0;
+            double m = wv::allmax16(v);
+            unsigned long long bal = wv::ballot(v == m);
+            int msk = (int)((bal >> (grp * GROUP)) & 0xFFFFull);
+            int kp = wv::ffs32(msk) - 1;          // first row holding the maximum
+            int src = lig_eq<k>() ? kp : ((lig == kp) ? k : lig);   // interchange rows k <-> kp
+            sfor<k, NN>([&](auto jc) ACME_LAMBDA {  // columns < k are dead
+                constexpr int j = decltype(jc)::value;
+                a[j] = wv::shfl16(a[j], src);
+            });
+            orig = wv::shfl16(orig, src);
             double piv = wv::bcast16<k>(a[k]);
-            double inv = wv::keep(wv::recip(piv));
-            if (wv::ballot(lig_in<k + 1, NN>() && fabs(a[k]) > fabs(piv))) {
-                double v = lig_in<k, NN>() ? fabs(a[k]) : -1.0;
-                double m = wv::allmax16(v);
-                unsigned long long bal = wv::ballot(v == m);
-                int msk = (int)((bal >> (grp * GROUP)) & 0xFFFFull);
-                int kp = wv::ffs32(msk) - 1;      // first row holding the maximum
-                if (wv::ballot(kp != k)) {        // row interchange k <-> kp
-                    int src = lig_eq<k>() ? kp : ((lig == kp) ? k : lig);
-                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                        constexpr int j = decltype(jc)::value;
-                        a[j] = wv::shfl16(a[j], src);
-                    });
-                    orig = wv::shfl16(orig, src);
-                    if (AUG) b = wv::shfl16(b, src);
-                    piv = wv::bcast16<k>(a[k]);
-                    inv = wv::recip(piv);
-                }
-            }
             ok = ok && (piv != 0.0);
-            double lm = lig_gt<k>() ? a[k] * inv : 0.0;   // multipliers l_ik, 0 on rows <= k
-            a[k] = lig_gt<k>() ? lm : (lig_eq<k>() ? inv : a[k]);
+            double lm = lig_gt<k>() ? a[k] * wv::recip(piv) : 0.0;   // l_ik, 0 on rows <= k
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
                 a[j] = fma(-lm, wv::bcast16<k>(a[j]), a[j]);
             });
-            if (AUG) b = fma(-lm, wv::bcast16<k>(b), b);
         });
         return ok;
     }
@@ -250,6 +243,32 @@ ACME_DEV double rcv(const RowDesc &rd, int c) { return rd.rc[c * GROUP]; }
 // the hoisted exponentials exp(e[0]*k[0]), exp(e[1]*k[1]).
 //   diode (v, i) | bjt row0 (vE, vC, iE), row1 (vE, vC, iC) | pot row0 (v1, i1, pos),
 //   row1 (v2, i2, pos) | mosfet (vgs, vds, id) | tanh op-amp (vi, vo) | JA (q1..q4)
+// Branch-free evaluation of the common kinds (diode, Ebers-Moll BJT, potentiometer, padding rows)
+// from per-row constants -- see UnifiedRowConst in acme_common.h.  Every lane runs the same 16
+// instructions whatever element its row belongs to; the kind-by-kind version below costs ~60
+// instructions in nested exec-masked regions.  xA/xB are the exponentials' arguments (0 for
+// rows without a junction: exp(0) - 1 = 0).
+template <int NT>
+ACME_DEV void eval_row_unified(const RowDesc &rd, const double (&e)[NT], double exA, double exB,
+                               double &res, double (&tv)[NT]) {
+    static_assert(NT >= 3, "unified rows use three q entries");
+    const double cA = rd.k[UR_CA - UR_SA], cB = rd.k[UR_CB - UR_SA], dA = rd.k[UR_DA - UR_SA],
+                 dB = rd.k[UR_DB - UR_SA], h = rd.k[UR_H - UR_SA];
+    const double g0 = rd.rc[UR_G0 * GROUP], g1 = rd.rc[UR_G1 * GROUP], g2 = rd.rc[UR_G2 * GROUP],
+                 w0 = rd.rc[UR_W0 * GROUP], w1 = rd.rc[UR_W1 * GROUP];
+    const double hw = h * fma(w1, e[2], w0);
+    double r = cA * (exA - 1.0);
+    r = fma(cB, exB - 1.0, r);
+    r = fma(g0, e[0], r);
+    r = fma(g1, e[1], r);
+    r = fma(g2, e[2], r);
+    res = fma(hw, e[1], r);
+    tv[0] = fma(dA, exA, g0);
+    tv[1] = fma(dB, exB, g1 + hw);
+    tv[2] = fma(h, e[1], g2);
+    for (int t = 3; t < NT; ++t) tv[t] = 0.0;
+}
+
 template <bool RARE, int NT>
 ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, double exB,
                        double &res, double (&tv)[NT]) {
@@ -461,7 +480,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         rd.erow = rowi_s[1 * GROUP + rowid];
         rd.flags = rowi_s[2 * GROUP + rowid];
         rd.rc = rowc_s + rowid;
-        sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
+        // register-cached constants: the kind-by-kind evaluation (RARE shapes) wants rc[0..7],
+        // the unified rows sA sB cA cB dA dB h
+        constexpr int K0 = S::RARE ? 0 : UR_SA;
+        sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[(K0 + decltype(c_)::value) * GROUP]; });
     };
     load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
@@ -480,7 +502,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double res = 0.0;
     double tv[NT];
 
-    double *st = A.state + (valid ? inst : 0) * S::STATE;
+    const double *st = A.state + (valid ? inst : 0) * S::STATE;
     sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         int i = s * GROUP + lig;
@@ -500,6 +522,24 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     });
     const int nsub = (NN > 0) ? A.nsub : 0;
 
+    // ---- ACME_TIMING builds (tools/timing_probe.py): shader-clock time per code region ---
+#ifdef ACME_TIMING
+    enum { TB_POST, TB_PRE, TB_SETUP, TB_EVAL, TB_PIVOT, TB_GJ0, TB_GJP, TB_STORE, TB_GLUE, TB_HOMO,
+           TB_E1, TB_E2, TB_E3, TB_N };
+    long long tb[TB_N] = {0};
+    long long tmark = (long long)__builtin_readcyclecounter();
+#define ACME_T(bucket) do { wv::sched_fence(); long long t_ = (long long)__builtin_readcyclecounter(); \
+                            tb[bucket] += t_ - tmark; tmark = t_; wv::sched_fence(); } while (0)
+#ifdef ACME_TIMING_FINE
+#define ACME_T2(bucket) ACME_T(bucket)
+#else
+#define ACME_T2(bucket) do { } while (0)
+#endif
+#else
+#define ACME_T(bucket) do { } while (0)
+#define ACME_T2(bucket) do { } while (0)
+#endif
+
 #ifdef ACME_PROFILE_PIECES
     double prof_sink = 0.0;
 #endif
@@ -518,6 +558,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 acc = fma(Ms[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
             });
             pf[t] = acc;
+            wv::sched_fence();   // bound the number of LDS loads in flight (register pressure)
         });
     };
 
@@ -540,12 +581,22 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             });
             e[t] = acc;
         });
+        ACME_T2(TB_E1);
         // hoisted exponentials: diode exp(v/(eta vT)), BJT exp(vE/..), exp(vC/..)
-        const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
-        double exA = exp_junction(expo ? e[0] * rd.k[0] : 0.0);
-        double exB = has_bjt ? exp_junction(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0) : 1.0;
-        eval_row<S::RARE, NT>(rd, e, exA, exB, res, tv);
-        double chk = res * 0.0;
+        double exA, exB;
+        if constexpr (S::RARE) {
+            const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
+            exA = exp_junction(expo ? e[0] * rd.k[0] : 0.0);
+            exB = has_bjt ? exp_junction(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0) : 1.0;
+            ACME_T2(TB_E2);
+            eval_row<true, NT>(rd, e, exA, exB, res, tv);
+        } else {
+            exA = exp_junction(e[0] * rd.k[0]);                       // sA = 0: exp(0) = 1
+            exB = has_bjt ? exp_junction(e[1] * rd.k[1]) : 1.0;       // sB = 0 likewise
+            ACME_T2(TB_E2);
+            eval_row_unified<NT>(rd, e, exA, exB, res, tv);
+        }
+        ACME_T2(TB_E3);
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
             constexpr int j = decltype(jc)::value;
             double acc = tv[0] * Ms[L.fqr + j * GROUP + rowid];
@@ -554,10 +605,11 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 acc = fma(tv[t], Ms[L.fqr + (t * NN + j) * GROUP + rowid], acc);
             });
             a[j] = acc;
-            chk = fma(acc, 0.0, chk);
         });
-        // non-finite anywhere in this instance's res / J ?
-        unsigned long long bad = wv::ballot(lig < NN && !(chk == 0.0));
+        // non-finite anywhere in this instance's res / J ?  (src/solvers.jl:220)  A sum is
+        // non-finite as soon as one term is (inf - inf = NaN); summed pairwise, not as a chain
+        double chk = res + tree_sum<0, NN>(a);
+        unsigned long long bad = wv::ballot(lig < NN && !(fabs(chk) <= 1.79769313486231570815e308));
         return ((bad >> (grp * GROUP)) & 0xFFFFull) == 0ull;
     };
 
@@ -586,41 +638,60 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         load_rowdesc();
     };
 
-    // Solve J dz = res for the J / res of the latest evaluate!(z) (left in a[] / res) by
-    // in-place Gauss-Jordan; with `with_jp` the columns of Jp ride along and the lanes flagged
-    // `store` write their row of J^-1*Jp to the origin slab (set_extrapolation_origin,
-    // src/solvers.jl:191-196).  If the in-place pivots were not the maxima (~4-8 % of calls)
-    // a partially pivoted LU of a fresh J supplies the pivot order, the lanes adopt it and the
-    // elimination is repeated in the new order.  Returns false for a singular J.
-    auto eliminate = [&](bool with_jp, double &dz, bool store = true) ACME_LAMBDA -> bool {
-        bool ok = true;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+    // One Newton linearisation at z: evaluate! (res, J), then solve J dz = res by in-place
+    // Gauss-Jordan.  An iterate whose residual is already below tol is going to be accepted and
+    // become the new extrapolation origin (hasconverged looks at the residual alone,
+    // src/solvers.jl:203,225-233); for it -- `want`, or `force` -- the columns of Jp ride along
+    // and the instance's lanes write their rows of J^-1*Jp to the origin slab
+    // (set_extrapolation_origin, src/solvers.jl:191-196).  If the in-place pivots were not the
+    // maxima (a few % of the calls) the retry loop evaluates again, runs the reference's
+    // partially pivoted LU to learn the pivot order, lets the lanes adopt it, evaluates in the
+    // new order and eliminates again.  evaluate / pivot_order / solve_inplace each have ONE call
+    // site (code size, registers); `phase` is opaque so that the optimiser does not clone the
+    // body per phase.  finite: res and J finite; ok: J non-singular; small: |res| < tol.
+    auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
+        ok = true;
+        int phase = 0;   // 0: first try   1: learn the pivot order   2: retry in the new order
+        for (;;) {
+            phase = wv::opaque(phase);
+            finite = evaluate(zz);
+            ACME_T(TB_EVAL);
+            if (phase == 1) {
+                ok = LU::pivot_order(a, orig, lig, grp);
+                adopt();
+                phase = 2;
+                ACME_T(TB_PIVOT);
+                continue;
+            }
+            // only the boolean is needed, so no max-reduction -- one compare and a ballot; a NaN
+            // residual counts as not small
+            const unsigned long long big = wv::ballot(!(fabs(res) < A.tol)) & rows4((1ull << NN) - 1ull);
+            small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+            const bool want = force || (act && finite && small);
             unsigned long long viol;
             double jp[NPr];
             dz = res;
+            const bool with_jp = wv::ballot(want) != 0ull;
             if (with_jp) {
                 calc_jp(jp);
                 viol = LU::template solve_inplace<NP>(a, dz, jp);
+                ACME_T(TB_GJP);
             } else {
                 double none[1] = {0.0};
                 viol = LU::template solve_inplace<0>(a, dz, none);
+                ACME_T(TB_GJ0);
+            }
+            if (viol != 0ull && phase == 0) {
+                phase = 1;
+                continue;
             }
             const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
-            if (attempt == 1) ok = ok && !mine;
-            if (viol == 0ull || attempt == 1) {
-                if (with_jp && store && !mine && lig < NN)   // per-lane predicated LDS stores
-                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
-                break;
-            }
-            // pivot order changed (or J is singular): find it with the reference's partially
-            // pivoted LU on a fresh J, adopt it, evaluate again in the new order
-            (void)evaluate(z);
-            double dummy = 0.0;
-            ok = LU::template factor<false>(a, orig, lig, grp, dummy);
-            adopt();
-            (void)evaluate(z);
+            ok = ok && !mine;
+            if (with_jp && want && !mine && lig < NN)   // per-lane predicated LDS stores
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
+            ACME_T(TB_STORE);
+            break;
         }
-        return ok;
     };
 
     // switch the live solver context to sub-problem s / save it back
@@ -650,9 +721,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             enter_sub(sc);
             set_p(lp);
             z = lz;
-            (void)evaluate(z);
-            double fwd0;
-            (void)eliminate(true, fwd0);
+            bool f0, k0, s0;
+            double d0;
+            linearize(z, false, true, f0, k0, s0, d0);
             leave_sub(sc);
         }
     });
@@ -672,18 +743,13 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         z = sel(need, lz - t, z);
         bool act = need, conv = false;
         its = 0;
+        ACME_T(TB_SETUP);
         while (wv::ballot(act)) {
             its = act ? its + 1 : its;
-            bool finite = evaluate(z);
-            // hasconverged (resmaxabs < tol, src/solvers.jl:203): only the boolean is needed, so
-            // no max-reduction -- one compare and a ballot; a NaN residual counts as not small
-            const unsigned long long big = wv::ballot(!(fabs(res) < A.tol)) & rows4((1ull << NN) - 1ull);
-            const bool small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
-            // this iterate becomes the new extrapolation origin if it is accepted
-            const bool want = act && finite && small;
-            // setlhs! comes before the convergence test (:223-226): a singular J ends the solve
+            bool finite, ok, small;
             double dz;
-            const bool ok = eliminate(wv::ballot(want) != 0ull, dz, want);
+            linearize(z, act, false, finite, ok, small, dz);
+            const bool want = act && finite && ok && small;
             ACME_DBG("emu newton lane %d it %d act %d finite %d res %g z %.17g", lane, its, (int)act, (int)finite, res, z);
             bool stop_bad = act && (!finite || !ok);
             bool stop_conv = want && ok;
@@ -694,42 +760,41 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             bool step = act && !stop_bad && !stop_conv;
             z = sel(step, z - dz, z);
             act = step && (its < A.maxiter);
+            ACME_T(TB_GLUE);
         }
         return conv;
     };
 
     // ---- report words -------------------------------------------------------------------
-    long long n_warn = 0, first_nonconv = -1, first_nonfinite = -1, iters_total = 0;
-    int iters_max = 0;
+    // kept in LDS (one copy per instance, updated by the instance's lane 0 once per sample)
+    // rather than in registers of all 16 lanes: they are never needed inside the solver loop
+    long long *rbuf = reinterpret_cast<long long *>(ybuf + S::YBUF);
     bool dead = !valid;  // dead: the reference would have thrown at first_nonfinite
     if (valid) {
         const long long *rp = A.report + inst * RW_WORDS;
-        n_warn = rp[RW_NWARN];
-        first_nonconv = rp[RW_FIRST_NONCONV];
-        first_nonfinite = rp[RW_FIRST_NONFINITE];
-        iters_total = rp[RW_ITERS_TOTAL];
-        iters_max = (int)rp[RW_ITERS_MAX];
-        dead = first_nonfinite >= 0;
+        if (lig < RW_WORDS) rbuf[lig] = rp[lig];
+        dead = rp[RW_FIRST_NONFINITE] >= 0;
     }
+    wv::wave_fence();
 
     // ---- time loop ----------------------------------------------------------------------
     const bool solve_mode = A.p_in != nullptr;
     const long long T = solve_mode ? 1 : A.T;
     const int nu_io = A.nu_io, ny_io = A.ny_io;
-    const double *ug = A.u + (valid ? inst : 0) * T * nu_io;
-    double *yg = A.y + (valid ? inst : 0) * T * ny_io;
     // u tile: fetched for chunk 0 before the loop and for chunk c+1 during the LAST sample of
-    // chunk c, after its Newton solve -- so the staging registers are not live across the
-    // (register-hungry) solver loop; the ~1 us of HBM latency hides behind that sample's y/x
-    // update and is paid once per 16 samples
+    // chunk c: the loads are issued right after that sample's Newton solve, the tile is
+    // overwritten after its y/x update (the last readers of the old tile) -- the ~1 us of HBM
+    // latency hides behind that update and no staging register lives across the solver loop.
+    // (Global pointers are recomputed here, once per 16 samples, for the same reason.)
     double upre[S::NUR];
     auto fetch_u = [&](long long n0) ACME_LAMBDA {
+        const double *ug = A.u + ((valid ? inst : 0) * T + n0) * nu_io;
         long long cnt = T - n0;
         if (cnt > CHUNK) cnt = CHUNK;
         sfor<0, NU>([&](auto ic) ACME_LAMBDA {
             constexpr int i = decltype(ic)::value;
-            long long e = lig + GROUP * i;
-            upre[i] = (valid && e < cnt * nu_io) ? ug[n0 * nu_io + e] : 0.0;
+            int e = lig + GROUP * i;
+            upre[i] = (valid && e < (int)cnt * nu_io) ? ug[e] : 0.0;
         });
     };
     auto stage_u = [&]() ACME_LAMBDA {
@@ -750,6 +815,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         int cnt = (int)((T - n0 < CHUNK) ? (T - n0) : CHUNK);
         for (int m = 0; m < cnt; ++m) {
             const long long n = A.sample_base + n0 + m;
+            ACME_T(TB_POST);
             // the nonlinear sub-problems, one after another: later ones see the solutions of the
             // earlier ones through fqprev (src/ACME.jl:675-697)
             sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
@@ -783,6 +849,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 int mode = 0, its_sample = 0;
                 double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
                 ACME_DBG("sample %lld sub %d lane %d p %.17g x %.17g lp %.17g lz %.17g", n, s, lane, p, x[0], lp, lz);
+                ACME_T(TB_PRE);
                 while (wv::ballot(need)) {
                     int its;
                     bool c = base_solve(target, need, its);
@@ -811,6 +878,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                         pa = pa + ha * p;
                         target = sel(need, pa, target);
                     }
+                    ACME_T(TB_HOMO);
                 }
                 zs[s] = alive ? z : 0.0;
                 if (solve_mode) {   // hand the solver's answer back; no y, no state update
@@ -827,19 +895,25 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     if (wv::ballot(failed)) {
                         bool warn = failed && zfinite;
                         bool die = failed && !zfinite;
-                        n_warn += warn ? 1 : 0;
-                        first_nonconv = (warn && first_nonconv < 0) ? n : first_nonconv;
-                        first_nonfinite = (die && first_nonfinite < 0) ? n : first_nonfinite;
+                        if (lig == 0 && warn) {
+                            rbuf[RW_NWARN] += 1;
+                            if (rbuf[RW_FIRST_NONCONV] < 0) rbuf[RW_FIRST_NONCONV] = n;
+                        }
+                        if (lig == 0 && die && rbuf[RW_FIRST_NONFINITE] < 0) rbuf[RW_FIRST_NONFINITE] = n;
                         dead = dead || die;
                     }
-                    iters_total += alive ? its_sample : 0;
-                    iters_max = (alive && its_sample > iters_max) ? its_sample : iters_max;
+                    if (lig == 0 && alive) {
+                        rbuf[RW_ITERS_TOTAL] += its_sample;
+                        if (its_sample > rbuf[RW_ITERS_MAX]) rbuf[RW_ITERS_MAX] = its_sample;
+                    }
                 }
                 if (S::NSUB > 1) leave_sub(sc);
             });
             if (solve_mode) continue;
-            if (NU > 0 && m == cnt - 1 && n0 + CHUNK < T) fetch_u(n0 + CHUNK);
+            const bool refill = NU > 0 && m == cnt - 1 && n0 + CHUNK < T;
+            if (refill) fetch_u(n0 + CHUNK);
             const bool live = !dead;
+            wv::sched_fence();
             // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
             if (NY > 0) {
                 double yy = M[L.y0 + lig];
@@ -860,6 +934,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 });
                 if (lig < NY) ybuf[m * NY + lig] = live ? yy : (double)NAN;
             }
+            wv::sched_fence();
             // x = x0 + a*x + b*u + c*z  (src/ACME.jl:708-714)
             if (NX > 0) {
                 double xn[NXSr];
@@ -899,19 +974,27 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     x[s] = sel(live, xn[s], x[s]);
                 });
             }
+            if (refill) stage_u();
         }
         // flush the y tile, coalesced
         if (NY > 0 && !solve_mode) {
+            double *yg = A.y + ((valid ? inst : 0) * T + n0) * ny_io;
             wv::wave_fence();
             for (int e = lig; e < cnt * ny_io; e += GROUP)
-                if (valid) yg[n0 * ny_io + e] = ybuf[(e / ny_io) * NY + (e % ny_io)];
+                if (valid) yg[e] = ybuf[(e / ny_io) * NY + (e % ny_io)];
             wv::wave_fence();
         }
-        if (NU > 0 && n0 + CHUNK < T) stage_u();
     }
 
+#ifdef ACME_TIMING
+    ACME_T(TB_POST);
+    if (valid && lig == 0 && !solve_mode && T >= TB_N && NY > 0)   // bucket totals replace the first samples of y
+        for (int i = 0; i < TB_N; ++i) A.y[inst * T * ny_io + (long long)i * ny_io] = (double)tb[i];
+#endif
     // ---- write back state and report ----------------------------------------------------
+    wv::wave_fence();
     if (valid) {
+        double *st = A.state + inst * S::STATE;
         sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
             constexpr int s = decltype(sc)::value;
             int i = s * GROUP + lig;
@@ -923,17 +1006,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             if (NP > 0 && lig < NP) st[NX + s * NP + lig] = lps[s];
             if (NN > 0 && lig < NN) st[NX + NSUB * NP + s * NN + lig] = lzs[s];
         });
-        if (lig == 0 && !solve_mode) {
-            long long *rp = A.report + inst * RW_WORDS;
-            rp[RW_NWARN] = n_warn;
-            rp[RW_FIRST_NONCONV] = first_nonconv;
-            rp[RW_FIRST_NONFINITE] = first_nonfinite;
-            rp[RW_ITERS_TOTAL] = iters_total;
-            rp[RW_ITERS_MAX] = iters_max;
-#ifdef ACME_PROFILE_PIECES
-            if (prof_sink == 1.2345e300) rp[RW_ITERS_MAX] = -1;
-#endif
-        }
+        if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
     }
 }
 

@@ -122,6 +122,8 @@ inline bool describe_element(int kind, const double *p, int er, int q0_, double 
         rc[0] = 1 / (25e-3 * eta);
         rc[1] = is;
         rc[2] = is / (25e-3 * eta);
+        // res = is*(exp(v/(eta*vT)) - 1) - i
+        rc[UR_SA] = rc[0]; rc[UR_CA] = rc[1]; rc[UR_DA] = rc[2]; rc[UR_G1] = -1.0;
         break;
     }
     case EK_BJT: {  // src/elements.jl:323-401 -- (vE, vC, iE|iC)
@@ -158,6 +160,15 @@ inline bool describe_element(int kind, const double *p, int er, int q0_, double 
         P.has_bjt = 1;
         if (P.nterms < 3) P.nterms = 3;
         if (flags) P.rare_kinds = 1;  // Gummel-Poon terms live in the RARE build
+        // Ebers-Moll: row 0  (i_f - i_r) + i_f/bf - iE,   row 1  -(i_f - i_r) + i_r/br - iC
+        rc[UR_SA] = rc[0]; rc[UR_SB] = rc[1]; rc[UR_G2] = -1.0;
+        if (er == 0) {
+            rc[UR_CA] = rc[2] * (1 + rc[6]); rc[UR_CB] = -rc[3];
+            rc[UR_DA] = rc[4] * (1 + rc[6]); rc[UR_DB] = -rc[5];
+        } else {
+            rc[UR_CA] = -rc[2]; rc[UR_CB] = rc[3] * (1 + rc[7]);
+            rc[UR_DA] = -rc[4]; rc[UR_DB] = rc[5] * (1 + rc[7]);
+        }
         break;
     }
     case EK_POT:  // src/elements.jl:25-30 -- (v, i, pos) of this half
@@ -166,6 +177,10 @@ inline bool describe_element(int kind, const double *p, int er, int q0_, double 
         tcs[2] = q0_ + 4;
         rc[0] = p[0];
         if (P.nterms < 3) P.nterms = 3;
+        // res = v - r*w*i with w = pos (first half) or 1 - pos (second half); the reference's
+        // Jacobian has -r*i in the pos column of BOTH halves (src/elements.jl:28) -- kept
+        rc[UR_G0] = 1.0; rc[UR_H] = -p[0];
+        rc[UR_W0] = er == 0 ? 0.0 : 1.0; rc[UR_W1] = er == 0 ? 1.0 : -1.0;
         break;
     case EK_MOSFET: {  // src/elements.jl:444-479
         tcs[1] = q0_ + 1;
@@ -327,6 +342,7 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
             int qrow = s->nq + (r - s->nn);
             fqp[(size_t)r * S.nq + qrow] = 1.0;
             rowi[0 * GROUP + r] = RK_PAD;
+            rowc[(size_t)UR_G0 * GROUP + r] = 1.0;
             for (int t = 0; t < 4; ++t) rowi[(3 + t) * GROUP + r] = qrow;
         }
         // row-gathered copies of fq / pexp / q0 (see Layout): slot `pos` = the lane position of

@@ -62,6 +62,7 @@ ACME_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(
 // per-lane predicate from a wave-uniform 64-bit lane mask (compile-time constants become two
 // s_mov_b32 feeding v_cndmask directly: no v_cmp, no long-lived SGPR pair)
 ACME_DEV bool lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 // 1/x: v_rcp_f64 seed (~23 good bits) + two fused Newton steps -> within 1 ulp of the
 // correctly rounded reciprocal the reference's inv() returns; no div_scale/div_fmas/div_fixup
 // chain on the LU's critical path (pivots are never denormal in practice)
@@ -80,5 +81,15 @@ ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // optimisation barrier: the value must be materialised here (keeps a speculative computation
 // on the near side of a branch instead of being sunk below it)
 ACME_DEV double keep(double v) { asm volatile("" : "+v"(v)); return v; }
+// wave-uniform integer the optimiser must not reason about (stops it from cloning a big loop
+// body per value of a small state variable)
+ACME_DEV int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+// wave mask pinned in a scalar register pair here and now: keeps an OR-chain of ballots
+// sequential (left to itself the optimiser gathers all terms first and spills them)
+ACME_DEV unsigned long long pin(unsigned long long m) { asm volatile("" : "+s"(m)); return m; }
+// floating-point literal as a scalar-register operand instead of living in -- and being copied
+// between -- vector registers.  Deliberately NOT volatile: volatile asm statements keep their
+// program order, which serialised the two interleaved exp() polynomial chains (-5 %).
+ACME_DEV double sconst(double v) { asm("" : "+s"(v)); return v; }
 
 }  // namespace wv

@@ -23,7 +23,8 @@ import numpy as np
 from .model import SOLVER_IDS, CachingHomotopySolver, DiscreteModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libacme_hip.so")
+# ACME_HIP_LIB: developer override used to A/B kernel build variants (tools/variants.sh)
+DEFAULT_LIBRARY = os.environ.get("ACME_HIP_LIB") or os.path.join(_HERE, "csrc", "libacme_hip.so")
 
 ACME_MEM_HOST, ACME_MEM_DEVICE = 0, 1
 
