@@ -94,13 +94,6 @@ template <int K, int N> ACME_DEV bool lig_in() {                                
 
 ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 
-// pairwise sum of v[I..I+N-1] (depth log2 N instead of a chain of N dependent adds)
-template <int I, int N, int M> ACME_DEV double tree_sum(const double (&v)[M]) {
-    if constexpr (N <= 0) return 0.0;
-    else if constexpr (N == 1) return v[I];
-    else return tree_sum<I, N / 2>(v) + tree_sum<I + N / 2, N - N / 2>(v);
-}
-
 // exp(x) for the junction laws: k = rint(x*log2(e)), r = x - k*ln2 (two-part Cody-Waite),
 // degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18 relative), scale by 2^k with
 // ldexp (which also saturates to inf / flushes to 0 for out-of-range arguments).  About 1 ulp,
@@ -128,6 +121,37 @@ ACME_DEV double exp_junction(double x) {
     const double kc = fmin(fmax(k, -2100.0), 2100.0);
     return ldexp(p, (int)kc);
 }
+// two exponentials at once: the same arithmetic as exp_junction on each argument, written out
+// in lockstep so that the two dependency chains interleave and every coefficient is
+// materialised once for both
+ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb) {
+    using wv::sconst;
+    const double l2e = sconst(1.4426950408889634), ln2h = sconst(6.93147180369123816490e-01),
+                 ln2l = sconst(1.90821492927058770002e-10);
+    const double ka = rint(xa * l2e), kb = rint(xb * l2e);
+    double ra = fma(-ka, ln2h, xa), rb = fma(-kb, ln2h, xb);
+    ra = fma(-ka, ln2l, ra);
+    rb = fma(-kb, ln2l, rb);
+    double c = sconst(1.6059043836821613e-10), d = sconst(2.08767569878681e-09);
+    double pa = fma(ra, c, d), pb = fma(rb, c, d);
+#define ACME_EXP2_STEP(coef) do { const double c_ = (coef); pa = fma(pa, ra, c_); pb = fma(pb, rb, c_); } while (0)
+    ACME_EXP2_STEP(sconst(2.505210838544172e-08));
+    ACME_EXP2_STEP(sconst(2.755731922398589e-07));
+    ACME_EXP2_STEP(sconst(2.7557319223985893e-06));
+    ACME_EXP2_STEP(sconst(2.48015873015873e-05));
+    ACME_EXP2_STEP(sconst(1.984126984126984e-04));
+    ACME_EXP2_STEP(sconst(1.388888888888889e-03));
+    ACME_EXP2_STEP(sconst(8.333333333333333e-03));
+    ACME_EXP2_STEP(sconst(4.1666666666666664e-02));
+    ACME_EXP2_STEP(sconst(1.6666666666666666e-01));
+    ACME_EXP2_STEP(0.5);
+    ACME_EXP2_STEP(1.0);
+    ACME_EXP2_STEP(1.0);
+#undef ACME_EXP2_STEP
+    const double lo = sconst(-2100.0), hi = sconst(2100.0);
+    ea = ldexp(pa, (int)fmin(fmax(ka, lo), hi));
+    eb = ldexp(pb, (int)fmin(fmax(kb, lo), hi));
+}
 ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 
 // ---------------------------------------------------------------------------------------
@@ -152,38 +176,21 @@ template <int NN> struct RowLU {
         double dinv = 1.0;   // reciprocal of this lane's pivot
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
-            double piv = wv::bcast16<k>(a[k]);
+            double piv = wv::bcast16_safe<k>(a[k]);
             // scalar mask arithmetic only: rows k+1..NN-1 with a strictly larger candidate
             viol = wv::pin(viol | (wv::ballot(fabs(a[k]) > fabs(piv)) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
             double inv = wv::recip(piv);
-            double lm = lig_eq<k>() ? 0.0 : a[k] * inv;    // multipliers of every other row
             dinv = lig_eq<k>() ? inv : dinv;
-            // broadcasts of pivot row k in batches ahead of the FMAs that consume them (a
-            // dependent dpp->fma pair costs ~17 cycles, a batched one ~9); two batches keep
-            // the number of live temporaries at max(NN, NC + 1)
-            {
-                double bk[NN > 0 ? NN : 1];
-                sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    bk[j] = wv::bcast16<k>(a[j]);
-                });
-                wv::sched_fence();
-                sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    a[j] = fma(-lm, bk[j], a[j]);
-                });
-            }
-            {
-                double bc[NC > 0 ? NC : 1];
-                double bb = wv::bcast16<k>(b);
-                sfor<0, NC>([&](auto jc) ACME_LAMBDA { bc[decltype(jc)::value] = wv::bcast16<k>(c[decltype(jc)::value]); });
-                if (NC > 0) wv::sched_fence();
-                b = fma(-lm, bb, b);
-                sfor<0, NC>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    c[j] = fma(-lm, bc[j], c[j]);
-                });
-            }
+            // row update  a[j] -= l * (pivot row's a[j]),  b and c[] likewise: fused broadcast-FMAs
+            // in program order.  Step 0 reads registers the compiler's own code has just written
+            // (SAFE forms); from step 1 on, the previous write of each register is at least two
+            // of these statements back (see fmac_bcast_self).
+            const double nlm = lig_eq<k>() ? 0.0 : a[k] * -inv;    // -multiplier of every other row
+            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                wv::fmac_bcast_self<k, k == 0>(a[decltype(jc)::value], nlm);
+            });
+            wv::fmac_bcast_self<k, k == 0>(b, nlm);
+            sfor<0, NC>([&](auto jc) ACME_LAMBDA { wv::fmac_bcast_self<k, k == 0>(c[decltype(jc)::value], nlm); });
         });
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
@@ -570,6 +577,15 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         // lane forms its own, so no cross-lane exchange of q is needed
         double zb[NNr];
         sfor<0, NN>([&](auto jc) ACME_LAMBDA { zb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(zz); });
+        // this row's fq entries (used twice: q = pf + fq*z here, J = Jq*fq below)
+        double fqv[NT][NNr];
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+            constexpr int t = decltype(tc_)::value;
+            sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                fqv[t][j] = Ms[L.fqr + (t * NN + j) * GROUP + rowid];
+            });
+        });
         wv::sched_fence();
         double e[NT];
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
@@ -577,7 +593,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             double acc = pf[t];
             sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                acc = fma(Ms[L.fqr + (t * NN + j) * GROUP + rowid], zb[j], acc);
+                acc = fma(fqv[t][j], zb[j], acc);
             });
             e[t] = acc;
         });
@@ -591,25 +607,31 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             ACME_T2(TB_E2);
             eval_row<true, NT>(rd, e, exA, exB, res, tv);
         } else {
-            exA = exp_junction(e[0] * rd.k[0]);                       // sA = 0: exp(0) = 1
-            exB = has_bjt ? exp_junction(e[1] * rd.k[1]) : 1.0;       // sB = 0 likewise
+            if (has_bjt) {                                            // sA/sB = 0: exp(0) = 1
+                exp_junction2(e[0] * rd.k[0], e[1] * rd.k[1], exA, exB);
+            } else {
+                exA = exp_junction(e[0] * rd.k[0]);
+                exB = 1.0;
+            }
             ACME_T2(TB_E2);
             eval_row_unified<NT>(rd, e, exA, exB, res, tv);
         }
         ACME_T2(TB_E3);
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
             constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * Ms[L.fqr + j * GROUP + rowid];
+            double acc = tv[0] * fqv[0][j];
             sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
-                acc = fma(tv[t], Ms[L.fqr + (t * NN + j) * GROUP + rowid], acc);
+                acc = fma(tv[t], fqv[t][j], acc);
             });
             a[j] = acc;
         });
-        // non-finite anywhere in this instance's res / J ?  (src/solvers.jl:220)  A sum is
-        // non-finite as soon as one term is (inf - inf = NaN); summed pairwise, not as a chain
-        double chk = res + tree_sum<0, NN>(a);
-        unsigned long long bad = wv::ballot(lig < NN && !(fabs(chk) <= 1.79769313486231570815e308));
+        // non-finite anywhere in this instance's res / J ?  (src/solvers.jl:220)  0*x is 0 for
+        // finite x and NaN otherwise; a chain of 4-byte v_fmac (code size matters more here than
+        // the length of the dependency chain)
+        double chk = res * 0.0;
+        sfor<0, NN>([&](auto jc) ACME_LAMBDA { chk = fma(a[decltype(jc)::value], 0.0, chk); });
+        unsigned long long bad = wv::ballot(lig < NN && !(chk == 0.0));
         return ((bad >> (grp * GROUP)) & 0xFFFFull) == 0ull;
     };
 
@@ -741,28 +763,30 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             t = fma(ojp[j * OS], wv::bcast16<j>(dp), t);
         });
         z = sel(need, lz - t, z);
-        bool act = need, conv = false;
+        bool act = need, conv = false, accepted = false;
         its = 0;
         ACME_T(TB_SETUP);
         while (wv::ballot(act)) {
-            its = act ? its + 1 : its;
+            its += act ? 1 : 0;
             bool finite, ok, small;
             double dz;
             linearize(z, act, false, finite, ok, small, dz);
             const bool want = act && finite && ok && small;
             ACME_DBG("emu newton lane %d it %d act %d finite %d res %g z %.17g", lane, its, (int)act, (int)finite, res, z);
-            bool stop_bad = act && (!finite || !ok);
-            bool stop_conv = want && ok;
+            const bool stop_bad = act && (!finite || !ok);
             // hasconverged is evaluated on resmaxabs even after a singular-J return
-            conv = stop_bad ? (finite && small) : (stop_conv ? true : conv);
-            lz = sel(stop_conv, z, lz);
-            lp = sel(stop_conv, target, lp);
-            bool step = act && !stop_bad && !stop_conv;
+            conv = stop_bad ? (finite && small) : conv;
+            accepted = accepted || want;
+            const bool step = act && !stop_bad && !want;
             z = sel(step, z - dz, z);
             act = step && (its < A.maxiter);
             ACME_T(TB_GLUE);
         }
-        return conv;
+        // an accepted iterate stays frozen in z until the loop ends (only stepping lanes move):
+        // it becomes the new extrapolation origin (its J^-1*Jp rows were stored by linearize)
+        lz = sel(accepted, z, lz);
+        lp = sel(accepted, target, lp);
+        return conv || accepted;
     };
 
     // ---- report words -------------------------------------------------------------------

@@ -29,6 +29,30 @@ template <int K> ACME_DEV double bcast16(double v) {
     return __longlong_as_double(x);
 }
 template <int K> ACME_DEV int bcast16(int v) { return dpp_i<0x150 + K>(v); }
+
+// Fused broadcast-multiply-add  acc += (lane K of acc's row) * mul  as ONE v_fmac_f64_dpp
+// (8 bytes, one issue slot) instead of v_mov_b64_dpp + v_fmac_f64 (12 bytes, two slots): per-wave
+// instruction fetch and issue, not the FP64 pipe, bound the elimination loops.
+// A DPP read needs 2 wait states after a VALU write of its source.  The compiler's hazard
+// recogniser does not look inside inline asm, so the order is made explicit: these statements
+// are volatile (kept in program order), callers arrange that at least two of them -- or an
+// unrelated dependent chain -- sit between a write and the DPP read of the same register, and
+// use the SAFE forms (leading s_nop 1) wherever the producer may be compiler-scheduled code.
+template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mul) {
+    if (SAFE)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(mul), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(mul), "n"(K));
+}
+// bcast16<K> as a volatile statement with the two wait states built in
+template <int K> ACME_DEV double bcast16_safe(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
 // rotate right by R within each 16-lane row (row_ror:R; 32-bit halves, not legal on b64)
 template <int R> ACME_DEV double ror16(double v) {
     int lo = dpp_i<0x120 + R>(__double2loint(v));
@@ -66,6 +90,11 @@ ACME_DEV bool lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_b
 // 1/x: v_rcp_f64 seed (~23 good bits) + two fused Newton steps -> within 1 ulp of the
 // correctly rounded reciprocal the reference's inv() returns; no div_scale/div_fmas/div_fixup
 // chain on the LU's critical path (pivots are never denormal in practice)
+ACME_DEV double recip1(double d) {   // one Newton step: ~20 ulp (measured 2.2e-15 max)
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    return fma(x, e, x);
+}
 ACME_DEV double recip(double d) {
     double x = __builtin_amdgcn_rcp(d);
     double e = fma(-d, x, 1.0);
