@@ -71,6 +71,23 @@ def make_u(torch, dev, model, pots, amp, n, T):
     return u
 
 
+def pmc_traffic(workload, n, T):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/profile_gpu.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this
+    command), or None if no pass for this exact workload is on file.  Reads = 2 x FETCH_SIZE:
+    gfx950 tallies this kernel's coalesced reads at half their size (calibrated on the
+    known byte count of the u stream)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            rec = json.load(fh)
+    except OSError:
+        return None
+    for r in rec.get("runs", []):
+        if r.get("workload") == workload and r.get("instances") == n and r.get("samples") == T:
+            return 1024.0 * (2.0 * r["fetch_size_kb_per_launch"] + r["write_size_kb_per_launch"])
+    return None
+
+
 def algorithmic_bytes(model, n, T):
     """8*(nu+ny) bytes per instance*sample + per-launch state/model traffic."""
     s = model.subs[0] if model.subs else None
@@ -266,10 +283,11 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, n_per_gpu, T),
+                "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
                 "kernel": "acme_run_kernel<Shape<%d,%d,%d,%d,%d,%d>>" % runner.kernel_shape(),
                 "kernel_ms": last_ms, "algorithmic_bytes_per_launch": abytes,
-                "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY 8d); fp64 figure below",
+                "note": "path is bound by per-wave instruction issue/fetch, not by HBM (DESIGN.md 2); fp64 figure below",
                 "fp64_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
                 / (last_ms * 1e-3) / 1e12 if model.subs else None,
                 "fp64_peak_tflops": FP64_PEAK_TFLOPS,

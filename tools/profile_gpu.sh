@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline $*"
+export BENCH_ARGS="$*"
 echo "== kernel trace + stats"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
 echo "== pmc: HBM read"
@@ -38,6 +39,7 @@ for f in sorted(glob.glob(out + "/trace/*.db")):
                          "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) "
                          "from kernels where name like '%acme%' group by name"):
         print("dispatches=%d avg_us=%.1f min_us=%.1f max_us=%.1f vgpr=%s agpr=%s sgpr=%s lds_bytes=%s scratch=%s grid=%s wg=%s" % r[1:])
+vals = {}
 for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in sorted(glob.glob(out + f"/{grp}/*.db")):
         con = sqlite3.connect(f)
@@ -45,4 +47,17 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for r in con.execute("select counter_name, count(*), avg(value) from counters_collection "
                              "where kernel_name like '%acme%' group by counter_name"):
             print("%-28s dispatches=%d per_dispatch=%.6g" % r)
+            vals[r[0]] = r[2]
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    import json, shlex
+    a = shlex.split(os.environ.get("BENCH_ARGS", ""))
+    def opt(name, default):
+        return a[a.index(name) + 1] if name in a else default
+    rec = {"runs": [{"workload": opt("--workload", "superover_grid"), "instances": int(opt("--instances", 8192)),
+                     "samples": int(opt("--samples", 44100)),
+                     "fetch_size_kb_per_launch": vals["FETCH_SIZE"], "write_size_kb_per_launch": vals["WRITE_SIZE"],
+                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the launches of "
+                               "python bench.py --no-cpu-baseline " + " ".join(a)}]}
+    with open(out + "/pmc_traffic.json", "w") as fh:
+        json.dump(rec, fh, indent=1)
 PY
