@@ -104,6 +104,9 @@ struct KArgs {
     double *y;               // [n_inst][T][ny_io]
     double *state;           // [n_inst][nx + np + nn] : x | last_p | last_z
     long long *report;       // [n_inst][RW_WORDS]
+    int *roworder;           // [n_inst][nsub_shape][16]: lane -> residual row assignment the lanes had
+                             // adopted when the previous launch ended (identity = the host hint); kept
+                             // so that a run split over several launches repeats the one-launch arithmetic
     long long n_inst;
     long long T;
     long long sample_base;   // global index of the first sample of this launch

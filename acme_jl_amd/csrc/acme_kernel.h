@@ -525,7 +525,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         lps[s] = (NP > 0 && valid && lig < NP) ? st[NX + s * NP + lig] : 0.0;
         lzs[s] = (NN > 0 && valid && lig < NN) ? st[NX + NSUB * NP + s * NN + lig] : 0.0;
         zs[s] = 0.0;
-        rowids[s] = lig;
+        rowids[s] = valid ? A.roworder[(inst * NSUB + s) * GROUP + lig] : lig;
     });
     const int nsub = (NN > 0) ? A.nsub : 0;
 
@@ -1029,6 +1029,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             constexpr int s = decltype(sc)::value;
             if (NP > 0 && lig < NP) st[NX + s * NP + lig] = lps[s];
             if (NN > 0 && lig < NN) st[NX + NSUB * NP + s * NN + lig] = lzs[s];
+            A.roworder[(inst * NSUB + s) * GROUP + lig] = rowids[s];
         });
         if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
     }

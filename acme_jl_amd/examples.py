@@ -42,55 +42,58 @@ def _pot(r, pos):
     return potentiometer(r) if pos is None else potentiometer(r, pos)
 
 
-def superover(drive=None, tone=None, level=None, sym=False):
+def superover(drive=None, tone=None, level=None, sym=False, value=None):
+    # value(name, nominal) -> value used for resistor / capacitor / pot-track `name`
+    # (component-tolerance Monte-Carlo, BASELINE config 4); default: nominal
+    V = (lambda name, nominal: nominal) if value is None else value
     circ = build([
         # power supply
         ("j3", voltagesource(9), {"+": "vcc", "-": "gnd"}),
         ("d4", diode(is_=12e-9, eta=2), {"-": "vcc", "+": "gnd"}),
-        ("c11", capacitor(100e-6), {1: "vcc", 2: "gnd"}),
-        ("r17", resistor(33e3), {1: "vcc", 2: "vb"}),
-        ("r18", resistor(33e3), {1: "vb", 2: "gnd"}),
-        ("c12", capacitor(47e-6), {1: "vb", 2: "gnd"}),
+        ("c11", capacitor(V("c11", 100e-6)), {1: "vcc", 2: "gnd"}),
+        ("r17", resistor(V("r17", 33e3)), {1: "vcc", 2: "vb"}),
+        ("r18", resistor(V("r18", 33e3)), {1: "vb", 2: "gnd"}),
+        ("c12", capacitor(V("c12", 47e-6)), {1: "vb", 2: "gnd"}),
         # input stage
         ("j1", voltagesource(), {"-": "gnd"}),
-        ("r1", resistor(2.2e6), {1: ("j1", "+"), 2: "gnd"}),
-        ("c1", capacitor(47e-9), {1: ("j1", "+")}),
-        ("r2", resistor(10e3), {1: ("c1", 2)}),
-        ("r3", resistor(470e3), {1: ("r2", 2), 2: "vb"}),
+        ("r1", resistor(V("r1", 2.2e6)), {1: ("j1", "+"), 2: "gnd"}),
+        ("c1", capacitor(V("c1", 47e-9)), {1: ("j1", "+")}),
+        ("r2", resistor(V("r2", 10e3)), {1: ("c1", 2)}),
+        ("r3", resistor(V("r3", 470e3)), {1: ("r2", 2), 2: "vb"}),
         ("q1", bjt("npn", is_=80e-15, bf=500, br=10), {"base": ("r2", 2), "collector": "vcc"}),
-        ("r4", resistor(10e3), {1: ("q1", "emitter"), 2: "gnd"}),
-        ("c2", capacitor(18e-9), {1: ("q1", "emitter")}),
-        ("r5", resistor(100e3), {1: ("c2", 2), 2: "vb"}),
+        ("r4", resistor(V("r4", 10e3)), {1: ("q1", "emitter"), 2: "gnd"}),
+        ("c2", capacitor(V("c2", 18e-9)), {1: ("q1", "emitter")}),
+        ("r5", resistor(V("r5", 100e3)), {1: ("c2", 2), 2: "vb"}),
         # distortion stage
         ("ic1a", opamp(), {"in+": ("c2", 2), "out-": "gnd"}),
         ("d1", diode(is_=4e-9, eta=2), {"-": ("ic1a", "out+"), "+": ("ic1a", "in-")}),
         ("d2", diode(is_=3e-9, eta=2), {"-": ("ic1a", "in-")}),
         ("d3", diode(is_=5e-9, eta=2), {"+": ("ic1a", "out+"), "-": ("d2", "+")}),
-        ("p1", _pot(1e6, drive), {2: [("p1", 3), ("ic1a", "out+")]}),
-        ("r6", resistor(33e3), {1: ("ic1a", "in-"), 2: ("p1", 1)}),
-        ("c4", capacitor(47e-9), {1: ("ic1a", "in-")}),
-        ("r7", resistor(4.7e3), {1: ("c4", 2), 2: "vb"}),
+        ("p1", _pot(V("p1", 1e6), drive), {2: [("p1", 3), ("ic1a", "out+")]}),
+        ("r6", resistor(V("r6", 33e3)), {1: ("ic1a", "in-"), 2: ("p1", 1)}),
+        ("c4", capacitor(V("c4", 47e-9)), {1: ("ic1a", "in-")}),
+        ("r7", resistor(V("r7", 4.7e3)), {1: ("c4", 2), 2: "vb"}),
         # tone control stage
-        ("r8", resistor(10e3), {1: ("ic1a", "out+")}),
+        ("r8", resistor(V("r8", 10e3)), {1: ("ic1a", "out+")}),
         ("ic1b", opamp(), {"in+": ("r8", 2), "out-": "gnd"}),
-        ("c5", capacitor(18e-9), {1: ("ic1b", "in+"), 2: "gnd"}),
-        ("r10", resistor(10e3), {1: ("ic1b", "out+"), 2: ("ic1b", "in-")}),
-        ("c7", capacitor(10e-9), {1: ("ic1b", "out+"), 2: ("ic1b", "in-")}),
-        ("p2", _pot(20e3, tone), {1: ("ic1b", "in+"), 3: ("ic1b", "in-")}),
-        ("c6", capacitor(27e-9), {1: ("p2", 2)}),
-        ("r11", resistor(470), {1: ("c6", 2), 2: "gnd"}),
+        ("c5", capacitor(V("c5", 18e-9)), {1: ("ic1b", "in+"), 2: "gnd"}),
+        ("r10", resistor(V("r10", 10e3)), {1: ("ic1b", "out+"), 2: ("ic1b", "in-")}),
+        ("c7", capacitor(V("c7", 10e-9)), {1: ("ic1b", "out+"), 2: ("ic1b", "in-")}),
+        ("p2", _pot(V("p2", 20e3), tone), {1: ("ic1b", "in+"), 3: ("ic1b", "in-")}),
+        ("c6", capacitor(V("c6", 27e-9)), {1: ("p2", 2)}),
+        ("r11", resistor(V("r11", 470)), {1: ("c6", 2), 2: "gnd"}),
         # output stage
-        ("c8", capacitor(1e-3), {1: ("ic1b", "out+")}),
-        ("r12", resistor(4.7e3), {1: ("c8", 2)}),
-        ("p3", _pot(10e3, level), {1: "vb", 3: ("r12", 2)}),
-        ("r20", resistor(22e3), {1: ("p3", 2)}),
-        ("c9", capacitor(47e-9), {1: ("r20", 2)}),
-        ("r13", resistor(1e6), {1: ("c9", 2), 2: "vb"}),
+        ("c8", capacitor(V("c8", 1e-3)), {1: ("ic1b", "out+")}),
+        ("r12", resistor(V("r12", 4.7e3)), {1: ("c8", 2)}),
+        ("p3", _pot(V("p3", 10e3), level), {1: "vb", 3: ("r12", 2)}),
+        ("r20", resistor(V("r20", 22e3)), {1: ("p3", 2)}),
+        ("c9", capacitor(V("c9", 47e-9)), {1: ("r20", 2)}),
+        ("r13", resistor(V("r13", 1e6)), {1: ("c9", 2), 2: "vb"}),
         ("q2", bjt("npn", is_=80e-15, bf=500, br=10), {"base": ("c9", 2), "collector": "vcc"}),
-        ("r14", resistor(10e3), {1: ("q2", "emitter"), 2: "gnd"}),
-        ("r15", resistor(1e3), {1: ("q2", "emitter")}),
-        ("c10", capacitor(1e-6), {1: ("r15", 2)}),
-        ("r16", resistor(100e3), {1: ("c10", 2), 2: "gnd"}),
+        ("r14", resistor(V("r14", 10e3)), {1: ("q2", "emitter"), 2: "gnd"}),
+        ("r15", resistor(V("r15", 1e3)), {1: ("q2", "emitter")}),
+        ("c10", capacitor(V("c10", 1e-6)), {1: ("r15", 2)}),
+        ("r16", resistor(V("r16", 100e3)), {1: ("c10", 2), 2: "gnd"}),
         ("j2", voltageprobe(), {"+": ("c10", 2), "-": "gnd"}),
     ])
     if sym:

@@ -117,7 +117,9 @@ void acme_batch_destroy(acme_batch *b);
 
 /* per-instance matrices (Monte-Carlo component tolerances): instance i uses the matrices
  * of models[i]; all models must have the dimensions and element table of the batch's
- * model.  Only valid for batches created with per_instance_matrices = 1. */
+ * model.  The instances take the freshly constructed state of their model (x = 0, each
+ * solver's extrapolation origin at p = 0, z = the model's init_z; src/ACME.jl:145,253-259).
+ * Only valid for batches created with per_instance_matrices = 1. */
 int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
                             const acme_model *const *models);
 

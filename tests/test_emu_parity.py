@@ -103,6 +103,36 @@ def test_emulated_per_instance_matrices(emu_lib):
     assert np.abs(y[0] - y[4]).max() > 1e-4   # the instances really differ
 
 
+def test_emulated_monte_carlo_superover(emu_lib):
+    """BASELINE config 4 in miniature (component tolerances on the fixed-pot superover): every
+    instance must start from ITS model's initial solution, not the batch model's."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import sine
+    rng = np.random.Generator(np.random.PCG64(20250905))
+    models = [DiscreteModel(examples.superover(1.0, 1.0, 1.0, value=lambda n, v: v * (1 + 0.05 * rng.uniform(-1, 1))),
+                            Fraction(1, 44100)) for _ in range(3)]
+    u = np.tile(sine(160)[None, None, :], (3, 1, 1))
+    y = ModelRunner(models[0], 3, models=models, lib=emu_lib).run(u)
+    for k in range(3):
+        yref, _ = oracle_run(models[k], u[k:k + 1])
+        assert_close(y[k:k + 1], yref, rtol=1e-9)
+
+
+def test_emulated_split_run_is_bit_identical(emu_lib):
+    """run! over [0,T) equals run! over [0,a) then [a,T) bit for bit: besides (x, last_p, last_z)
+    the library keeps the pivot (row) order the lanes had adopted."""
+    m = load("superover_fixed")
+    u = sweep_inputs("superover_fixed", 4, 260)
+    from acme_jl_amd.runner import ModelRunner
+    y1 = ModelRunner(m, 4, lib=emu_lib).run(u)
+    r = ModelRunner(m, 4, lib=emu_lib)
+    y2 = np.concatenate([r.run(u[:, :, :97]), r.run(u[:, :, 97:])], axis=2)
+    assert np.array_equal(y1, y2)
+
+
 def test_emulated_tight_tolerance_parity(emu_lib):
     """With set_resabstol!(1e-13) on both sides stopping-test flips are harmless: the two
     implementations must agree to rounding level (helpers.RTOL_TIGHT)."""

@@ -20,6 +20,7 @@ def runner(hip_lib, model, n, **kw):
     ("superover_var", 33, 1024),
     ("birdie_fixed", 16, 2048),
     ("birdie_var", 18, 2048),
+    ("birdie_var_176k", 16, 4096),    # BASELINE config 5's model (fs = 176.4 kHz, variable vol)
     ("rc_ladder", 5, 512),
     ("sallenkey", 4, 512),
 ])
@@ -201,6 +202,57 @@ def test_full_size_properties(hip_lib):
     idx = np.linspace(0, N - 1, 8).astype(int)
     yref, _ = oracle_run(m, u[idx].cpu().numpy().transpose(0, 2, 1))
     assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
+
+
+def test_full_size_superover_grid(hip_lib):
+    """BASELINE config 3 (the bench workload: 8192-instance drive x tone x level grid of the
+    variable-pot superover) at full width, through size-independent properties plus spot parity:
+    block-split invariance, invariance under reordering whole wavefront groups, level pot only
+    scales the output stage, and 8 instances against the oracle."""
+    import torch
+    import bench
+    m = load("superover_var")
+    N, T = 8192, 1536
+    _, pots, amp = bench.grid_inputs("superover_grid", 0, 1, N, T)
+    u = bench.make_u(torch, torch.device("cuda"), m, pots, amp, N, T)
+    r1 = runner(hip_lib, m, N)
+    y1 = r1.run_torch(u)
+    r1.check()
+    r2 = runner(hip_lib, m, N)
+    y2 = torch.cat([r2.run_torch(u[:, a:b].contiguous()) for a, b in ((0, 17), (17, 1000), (1000, T))], dim=1)
+    assert torch.equal(y1, y2)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).cuda()
+    r3 = runner(hip_lib, m, N)
+    y3 = r3.run_torch(u[perm].contiguous())
+    # different wave-mates -> different wave-level loop trip counts, same per-instance arithmetic
+    assert torch.equal(y1[perm], y3)
+    assert torch.isfinite(y1).all()
+    idx = np.array([0, 255, 256, 1023, 4095, 4096, 7000, 8191])
+    un = u[idx].cpu().numpy().transpose(0, 2, 1)
+    yref, its = oracle_run(m, un)
+    assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
+    ra = r1.report_arrays()
+    assert (ra["n_warn"] == 0).all()
+
+
+def test_monte_carlo_per_instance_superover(hip_lib):
+    """BASELINE config 4 in miniature: fixed-pot superover with every resistor and capacitor
+    scaled by 1 + 0.05*U(-1,1) (PCG64 seed 20250905), one private model block per instance."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    rng = np.random.Generator(np.random.PCG64(20250905))
+    models = []
+    for k in range(6):
+        c = examples.superover(1.0, 1.0, 1.0, value=lambda name, v: v * (1 + 0.05 * rng.uniform(-1, 1)))
+        models.append(DiscreteModel(c, Fraction(1, 44100)))
+    u = np.tile(sine(800)[None, None, :], (6, 1, 1))
+    y = ModelRunner(models[0], 6, models=models, lib=hip_lib).run(u)
+    for k in range(6):
+        yref, _ = oracle_run(models[k], u[k:k + 1])
+        assert_close(y[k:k + 1], yref)
+    assert np.abs(y[0] - y[1]).max() > 1e-6      # the instances really are different circuits
 
 
 def trajectory_ps(m, u, every=7):
