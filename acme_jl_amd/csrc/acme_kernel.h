@@ -158,15 +158,23 @@ ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 // LinearSolver, row-per-lane (src/solvers.jl:46-132).  a[j] = element (lig, j).
 // ---------------------------------------------------------------------------------------
 template <int NN> struct RowLU {
+    // Threshold partial pivoting: the row already sitting in pivot position is kept as long as no
+    // later row would need a multiplier larger than this (element growth per step <= 1 + 4, the
+    // usual relaxed-pivoting trade; the reference's strict rule is the threshold 1).  With the
+    // strict rule ~5 % of the solves re-learnt the row order only because two candidates of
+    // nearly equal size had swapped ranks: +10 % run time for differences at rounding level.
+    // 4.0 is an inline constant of the ISA.
+    static constexpr double PIVOT_THRESHOLD = 4.0;
+
     // Gauss-Jordan elimination of [A | b | C] in the CURRENT row order, without looking for
-    // pivots -- valid whenever the rows already sit in pivot order, which is the normal case
-    // because lanes adopt the pivot order of the last factorisation that had to interchange
-    // rows (see wave_main).  Row-per-lane makes eliminating above the pivot free (all lanes
+    // pivots -- valid whenever the rows already sit in (threshold-)pivot order, which is the
+    // normal case because lanes adopt the pivot order of the last factorisation that had to
+    // interchange rows (see wave_main).  Row-per-lane makes eliminating above the pivot free (all lanes
     // execute the same FMA anyway), so there is no back-substitution: on return b = A^-1 b
     // (component k in lane k) and c[] = A^-1 C.  Same pivots and multipliers as the
     // reference's setlhs!/solve! (src/solvers.jl:46-132); the upper triangle is eliminated in
     // a different order, i.e. results agree to rounding.  Branch-free; returns a wave mask of
-    // the lanes that would have been a strictly larger pivot candidate (or got a non-finite result):
+    // the lanes whose multiplier exceeded PIVOT_THRESHOLD (or that got a non-finite result):
     // if the calling instance's bits are set the result is discarded and the caller redoes the
     // job after a partially pivoted factorisation (factor) has told it the pivot order.
     template <int NC>
@@ -177,8 +185,6 @@ template <int NN> struct RowLU {
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
             double piv = wv::bcast16_safe<k>(a[k]);
-            // scalar mask arithmetic only: rows k+1..NN-1 with a strictly larger candidate
-            viol = wv::pin(viol | (wv::ballot(fabs(a[k]) > fabs(piv)) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
             double inv = wv::recip(piv);
             dinv = lig_eq<k>() ? inv : dinv;
             // row update  a[j] -= l * (pivot row's a[j]),  b and c[] likewise: fused broadcast-FMAs
@@ -186,6 +192,8 @@ template <int NN> struct RowLU {
             // (SAFE forms); from step 1 on, the previous write of each register is at least two
             // of these statements back (see fmac_bcast_self).
             const double nlm = lig_eq<k>() ? 0.0 : a[k] * -inv;    // -multiplier of every other row
+            // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
+            viol = wv::pin(viol | (wv::ballot(fabs(nlm) > PIVOT_THRESHOLD) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
                 wv::fmac_bcast_self<k, k == 0>(a[decltype(jc)::value], nlm);
             });
@@ -674,12 +682,17 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
         ok = true;
         int phase = 0;   // 0: first try   1: learn the pivot order   2: retry in the new order
+        bool relearn = false;   // this instance tripped the threshold in phase 0
         for (;;) {
             phase = wv::opaque(phase);
             finite = evaluate(zz);
             ACME_T(TB_EVAL);
             if (phase == 1) {
-                ok = LU::pivot_order(a, orig, lig, grp);
+                // only the instances that tripped the threshold change their row order: what an
+                // instance computes must not depend on which other instances share its wave
+                const bool okp = LU::pivot_order(a, orig, lig, grp);
+                ok = relearn ? okp : true;
+                orig = relearn ? orig : lig;
                 adopt();
                 phase = 2;
                 ACME_T(TB_PIVOT);
@@ -703,11 +716,13 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 viol = LU::template solve_inplace<0>(a, dz, none);
                 ACME_T(TB_GJ0);
             }
+            viol &= wv::ballot(act || force);   // the other instances' results are not used
+            const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
             if (viol != 0ull && phase == 0) {
+                relearn = mine;
                 phase = 1;
                 continue;
             }
-            const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
             ok = ok && !mine;
             if (with_jp && want && !mine && lig < NN)   // per-lane predicated LDS stores
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
