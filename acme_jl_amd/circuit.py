@@ -22,6 +22,8 @@ import math
 from collections import OrderedDict
 from fractions import Fraction
 
+from .batchval import BVal
+
 # ---------------------------------------------------------------------------------
 # nonlinear element kinds: shared numbering with oracle/acme_ref.h and include/acme_hip.h
 # ---------------------------------------------------------------------------------
@@ -47,7 +49,7 @@ KIND_SHAPE = {
 
 
 def _frac(v):
-    if isinstance(v, Fraction):
+    if isinstance(v, (Fraction, BVal)):   # BVal: a batch of instances (montecarlo.derive_batch)
         return v
     if isinstance(v, bool):
         return Fraction(int(v))
@@ -62,7 +64,7 @@ def _frac(v):
 
 def _as_matrix(m):
     """Julia ``hcat(x)``: scalar -> 1x1, vector -> n x 1 column, matrix unchanged."""
-    if isinstance(m, (int, float, Fraction)):
+    if isinstance(m, (int, float, Fraction, BVal)):
         return [[_frac(m)]]
     m = list(m)
     if len(m) == 0:
@@ -162,9 +164,17 @@ def potentiometer(r, pos=None):
     if pos is not None:
         return Element(mv=_eye(2, -1), mi=[[r * pos, 0], [0, r * (1 - pos)]],
                        ports=[(1, 2), (2, 3)])
+    scale = 1
+    if isinstance(r, BVal):
+        # a batch of instances shares ONE element table: the table holds the structure instance's
+        # track resistance r_ref and the q rows carrying the currents are scaled by r / r_ref, so
+        # that  v - r_ref*pos*(i*r/r_ref) = v - r*pos*i  holds in every instance
+        r_ref = float(r)
+        scale = r / Fraction(r_ref)
+        r = r_ref
     return Element(
         mv=_eye(2) + _zeros(3, 2),
-        mi=_zeros(2, 2) + _eye(2) + _zeros(1, 2),
+        mi=_zeros(2, 2) + [[scale, 0], [0, scale]] + _zeros(1, 2),
         mq=_eye(5, -1), mu=[0, 0, 0, 0, -1],
         nonlinear=[(KIND_POT, [float(r)])],
         ports=[(1, 2), (2, 3)])

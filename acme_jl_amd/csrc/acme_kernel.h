@@ -164,7 +164,7 @@ template <int NN> struct RowLU {
     // strict rule ~5 % of the solves re-learnt the row order only because two candidates of
     // nearly equal size had swapped ranks: +10 % run time for differences at rounding level.
     // 4.0 is an inline constant of the ISA.
-    static constexpr double PIVOT_THRESHOLD = 4.0;
+        static constexpr double PIVOT_THRESHOLD = 4.0;
 
     // Gauss-Jordan elimination of [A | b | C] in the CURRENT row order, without looking for
     // pivots -- valid whenever the rows already sit in (threshold-)pivot order, which is the

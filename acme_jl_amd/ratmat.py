@@ -28,7 +28,7 @@ def eye(n):
 
 
 def frac_matrix(m):
-    return [[Fraction(v) for v in row] for row in m]
+    return [[v if hasattr(v, "n") and hasattr(v, "v") else Fraction(v) for v in row] for row in m]
 
 
 def transpose(m, ncols=None):

@@ -225,10 +225,23 @@ class ModelRunner:
             self.h = None
 
     # ---- per-instance matrices ----------------------------------------------------------
-    def set_models(self, first, models):
-        hs = [_ModelHandle(self.lib, m) for m in models]
-        arr = (C.c_void_p * len(hs))(*[m.h for m in hs])
-        self.lib.check(self.lib.L.acme_batch_set_matrices(self.h, first, len(hs), arr))
+    def set_models(self, first, models, chunk=1024):
+        """Give instances first.. their own model blocks (``acme_batch_set_matrices``); ``models``
+        is any iterable of DiscreteModels, e.g. ``montecarlo.BatchModels``."""
+        hs = []
+
+        def flush():
+            nonlocal first, hs
+            if hs:
+                arr = (C.c_void_p * len(hs))(*[m.h for m in hs])
+                self.lib.check(self.lib.L.acme_batch_set_matrices(self.h, first, len(hs), arr))
+                first += len(hs)
+                hs = []
+        for m in models:
+            hs.append(_ModelHandle(self.lib, m))
+            if len(hs) == chunk:
+                flush()
+        flush()
 
     # ---- run! ---------------------------------------------------------------------------
     def _check_io(self, u_rows, y_rows, ucols, ycols):

@@ -55,7 +55,24 @@ def grid_inputs(workload, rank, world, n_per_gpu, T):
     if workload == "diodeclipper_sweep":
         amp = 10.0 ** (-2 + 3 * idx / max(total - 1, 1))
         return "diodeclipper", None, amp
+    if workload == "superover_montecarlo":   # BASELINE config 4: models derived in montecarlo_models()
+        return "superover_fixed", None, 1.0
     raise ValueError(workload)
+
+
+def montecarlo_models(rank, n_per_gpu):
+    """BASELINE config 4: fixed-pot superover (1.0, 1.0, 1.0), every resistor, capacitor and pot
+    track scaled by 1 + 0.05*U(-1,1), semiconductors nominal.  Every rank derives its own shard
+    locally from (seed 20250905, rank) with the structure-replaying front end."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.montecarlo import derive_batch
+    make = lambda value: examples.superover(1.0, 1.0, 1.0, value=value)     # noqa: E731
+    nominal = {}
+    make(lambda name, v: nominal.setdefault(name, v))
+    rng = np.random.Generator(np.random.PCG64([20250905, rank]))
+    vals = {k: v * (1 + 0.05 * rng.uniform(-1, 1, n_per_gpu)) for k, v in nominal.items()}
+    return derive_batch(make, Fraction(1, 44100), vals)
 
 
 def make_u(torch, dev, model, pots, amp, n, T):
@@ -178,7 +195,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="superover_grid",
-                    choices=["superover_grid", "diodeclipper_sweep"])
+                    choices=["superover_grid", "diodeclipper_sweep", "superover_montecarlo"],
+                    help="superover_grid = BASELINE config 3 (the headline, default); diodeclipper_sweep = "
+                         "config 2; superover_montecarlo = config 4 (per-instance model blocks)")
     ap.add_argument("--instances", type=int, default=None, help="instances per GPU")
     ap.add_argument("--samples", type=int, default=FS, help="samples per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,7 +225,7 @@ def main():
     from acme_jl_amd.model import DiscreteModel
     from acme_jl_amd.runner import ModelRunner
 
-    n_per_gpu = args.instances or (8192 if args.workload == "superover_grid" else 4096)
+    n_per_gpu = args.instances or (4096 if args.workload == "diodeclipper_sweep" else 8192)
     T = args.samples
     fixture, pots, amp = grid_inputs(args.workload, rank, world, n_per_gpu, T)
     # rank 0 owns the model block; everyone else receives it over RCCL (xGMI)
@@ -214,7 +233,17 @@ def main():
         if rank == 0 else None
     model = broadcast_model(model, src=0, device=dev) if world > 1 else model
 
-    runner = ModelRunner(model, n_per_gpu, device=local_rank)
+    setup = {}
+    if args.workload == "superover_montecarlo":
+        t0 = time.perf_counter()
+        batch = montecarlo_models(rank, n_per_gpu)
+        setup["derive_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        model = batch.model(0)
+        runner = ModelRunner(model, n_per_gpu, device=local_rank, models=batch)
+        setup["upload_s"] = time.perf_counter() - t0
+    else:
+        runner = ModelRunner(model, n_per_gpu, device=local_rank)
     u = make_u(torch, dev, model, pots, amp, n_per_gpu, T)
     y = torch.empty((n_per_gpu, T, model.ny), dtype=torch.float64, device=dev)
 
@@ -263,8 +292,8 @@ def main():
         abytes = algorithmic_bytes(model, n_per_gpu, T)
         achieved = abytes / (last_ms * 1e-3) / 1e9
         out = {
-            "metric": "circuit-instance*samples/sec (superover, 44.1 kHz)"
-            if args.workload == "superover_grid" else "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)",
+            "metric": "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)"
+            if args.workload == "diodeclipper_sweep" else "circuit-instance*samples/sec (superover, 44.1 kHz)",
             "value": value, "unit": "circuit-instance*samples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -275,11 +304,16 @@ def main():
                              f"(drive=i/{n_per_gpu * world // 256}, tone,level=linspace(0,1,16)), "
                              "1 kHz unit sine")
                 if args.workload == "superover_grid" else
+                (f"examples/superover.jl fixed pots (nn=7,nq=14,np=5,nx=11,nu=1), {n_per_gpu} Monte-Carlo "
+                 "instances per GPU: R, C, pot tracks * (1 + 0.05 U(-1,1)), PCG64 seed 20250905, one model "
+                 "block per instance; 1 kHz unit sine")
+                if args.workload == "superover_montecarlo" else
                 f"examples/diodeclipper.jl, {n_per_gpu}-instance amplitude sweep 10mV..10V per GPU",
                 "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": FS,
                 "solver": model.solver, "parallelism": f"instance-sharded x{world}",
                 "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,
                 "n_warn": n_warn, "n_nonfinite_instances": n_dead, "y_abs_sum_rank0": checksum,
+                **({"host_setup": setup} if setup else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -236,23 +236,31 @@ def test_full_size_superover_grid(hip_lib):
 
 
 def test_monte_carlo_per_instance_superover(hip_lib):
-    """BASELINE config 4 in miniature: fixed-pot superover with every resistor and capacitor
-    scaled by 1 + 0.05*U(-1,1) (PCG64 seed 20250905), one private model block per instance."""
+    """BASELINE config 4 in miniature: fixed-pot superover with every resistor, capacitor and pot
+    track scaled by 1 + 0.05*U(-1,1) (PCG64 seed 20250905), one private model block per instance.
+    The blocks come from the structure-replaying batch front end (acme_jl_amd.montecarlo); the
+    oracle runs on models derived exactly, one by one, from the same component values."""
     from fractions import Fraction
     from acme_jl_amd import examples
     from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.montecarlo import derive_batch
     from acme_jl_amd.runner import ModelRunner
+    make = lambda value: examples.superover(1.0, 1.0, 1.0, value=value)     # noqa: E731
+    nominal = {}
+    make(lambda name, v: nominal.setdefault(name, v))
     rng = np.random.Generator(np.random.PCG64(20250905))
-    models = []
-    for k in range(6):
-        c = examples.superover(1.0, 1.0, 1.0, value=lambda name, v: v * (1 + 0.05 * rng.uniform(-1, 1)))
-        models.append(DiscreteModel(c, Fraction(1, 44100)))
-    u = np.tile(sine(800)[None, None, :], (6, 1, 1))
-    y = ModelRunner(models[0], 6, models=models, lib=hip_lib).run(u)
-    for k in range(6):
-        yref, _ = oracle_run(models[k], u[k:k + 1])
+    N = 40
+    vals = {k: v * (1 + 0.05 * rng.uniform(-1, 1, N)) for k, v in nominal.items()}
+    batch = derive_batch(make, Fraction(1, 44100), vals)
+    u = np.tile(sine(800)[None, None, :], (N, 1, 1))
+    r = ModelRunner(batch.model(0), N, models=batch, lib=hip_lib)
+    y = r.run(u)
+    for k in (0, 7, 16, 39):
+        exact = DiscreteModel(make(lambda name, v: float(vals[name][k])), Fraction(1, 44100))
+        yref, _ = oracle_run(exact, u[k:k + 1])
         assert_close(y[k:k + 1], yref)
     assert np.abs(y[0] - y[1]).max() > 1e-6      # the instances really are different circuits
+    assert (r.report_arrays()["n_warn"] == 0).all()
 
 
 def trajectory_ps(m, u, every=7):
