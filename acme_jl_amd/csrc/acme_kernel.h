@@ -184,7 +184,10 @@ template <int NN> struct RowLU {
         double dinv = 1.0;   // reciprocal of this lane's pivot
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
-            double piv = wv::bcast16_safe<k>(a[k]);
+            // a[k] was written by the first fused operation of step k-1; NN-k-1 more of them, the
+            // one on b and NC on c[] followed: two are enough wait states for this DPP read
+            constexpr bool far_enough = k > 0 && (NN - k + NC >= 2);
+            double piv = wv::bcast16_ordered<k, !far_enough>(a[k]);
             double inv = wv::recip(piv);
             dinv = lig_eq<k>() ? inv : dinv;
             // row update  a[j] -= l * (pivot row's a[j]),  b and c[] likewise: fused broadcast-FMAs

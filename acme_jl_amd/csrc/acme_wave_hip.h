@@ -46,11 +46,16 @@ template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mu
         asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
                      : "+v"(acc) : "v"(mul), "n"(K));
 }
-// bcast16<K> as a volatile statement with the two wait states built in
-template <int K> ACME_DEV double bcast16_safe(double v) {
+// bcast16<K> as a volatile statement (ordered with the fused operations); SAFE: with the two wait
+// states built in
+template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) {
     double r;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "=v"(r) : "v"(v), "n"(K));
+    if (SAFE)
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "=v"(r) : "v"(v), "n"(K));
+    else
+        asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "=v"(r) : "v"(v), "n"(K));
     return r;
 }
 // rotate right by R within each 16-lane row (row_ror:R; 32-bit halves, not legal on b64)
@@ -87,21 +92,17 @@ ACME_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(
 // s_mov_b32 feeding v_cndmask directly: no v_cmp, no long-lived SGPR pair)
 ACME_DEV bool lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
-// 1/x: v_rcp_f64 seed (~23 good bits) + two fused Newton steps -> within 1 ulp of the
-// correctly rounded reciprocal the reference's inv() returns; no div_scale/div_fmas/div_fixup
-// chain on the LU's critical path (pivots are never denormal in practice)
-ACME_DEV double recip1(double d) {   // one Newton step: ~20 ulp (measured 2.2e-15 max)
-    double x = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, x, 1.0);
-    return fma(x, e, x);
-}
+// 1/x: v_rcp_f64 seed (relative error 2^-24.4, measured: tools/ubench/rcpacc.hip) refined by one
+// cubically convergent step  x (1 + e + e^2),  e = 1 - d x  (truncation e^3 = 2^-73): 3 fused
+// operations, 1.00 ulp worst case against the correctly rounded reciprocal the reference's inv()
+// returns (tools/ubench/rcp3.hip; two quadratic Newton steps need 4 for the same result); no
+// div_scale/div_fmas/div_fixup chain on the elimination's critical path (pivots are never
+// denormal in practice)
 ACME_DEV double recip(double d) {
     double x = __builtin_amdgcn_rcp(d);
     double e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    return x;
+    e = fma(e, e, e);
+    return fma(x, e, x);
 }
 ACME_DEV int ffs32(int v) { return __ffs(v); }
 // scheduling fence: nothing is moved across (used to keep a batch of DPP broadcasts ahead of

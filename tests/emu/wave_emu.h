@@ -173,7 +173,7 @@ template <int K> ACME_DEV int bcast16(int v) {
     return (int)(int64_t)emu::exchange((uint64_t)(int64_t)v, (lane & ~15) + K, 200 + K);
 }
 template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mul) { acc = fma(bcast16<K>(acc), mul, acc); }
-template <int K> ACME_DEV double bcast16_safe(double v) { return bcast16<K>(v); }
+template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) { return bcast16<K>(v); }
 template <int R> ACME_DEV double ror16(double v) {
     int lane = tid() & 63;
     // row_ror:R -- lane i receives the value of lane (i - R) mod 16 of its row
@@ -198,7 +198,6 @@ ACME_DEV double shfl16(double v, int src) {
 }
 ACME_DEV unsigned long long ballot(bool p) { return emu::ballot_bits(p, 500); }
 ACME_DEV int ffs32(int v) { return __builtin_ffs(v); }
-ACME_DEV double recip1(double d) { return 1.0 / d; }
 ACME_DEV double recip(double d) { if ((tid() & 63) == 0) emu::g_count_recip++; return 1.0 / d; }
 ACME_DEV double keep(double v) { return v; }
 ACME_DEV int opaque(int v) { return v; }
