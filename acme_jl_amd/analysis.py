@@ -1,4 +1,4 @@
-"""steadystate / steadystate! on the batched GPU solver (src/ACME.jl:474-503).
+"""steadystate / steadystate! / linearize on the batched GPU solver (src/ACME.jl:474-550).
 
 The reference solves, per sub-problem, a *derived* nonlinear equation whose q-offset and fq
 fold the steady-state condition x = a x + b u + c z + x0 into the junction equations, with a
@@ -71,3 +71,43 @@ def steadystate_(runner, u=None):
         X = steadystate(m, U, lib=runner.lib)
     runner.set_state(x=X)
     return X
+
+
+def linearize(model, usteady=None, lib=None, device=None):
+    """``linearize(model, usteady)`` (src/ACME.jl:505-550, src/solvers.jl:407-414): the small-signal
+    linear ``DiscreteModel`` around the steady state for the constant input ``usteady``.
+
+    The two nonlinear solves (steady state at tolerance 1e-15, then ``solve(solver, psteady)`` with
+    the model's own solver settings) run on the GPU; ``get_extrapolation_jacobian`` = -J \\ Jp at
+    the solution and the assembly of the linear model are a handful of small dense products on the
+    host, as they are LAPACK calls in the reference."""
+    from .hostsolve import eval_table
+    if len(model.subs) > 1:
+        raise AcmeError("linearize on the GPU supports a single nonlinear sub-problem")
+    u = np.zeros(model.nu) if usteady is None else np.asarray(usteady, dtype=np.float64)
+    xs = steadystate(model, u, lib=lib, device=device)
+    x0, a, b = model.x0.copy(), model.a.copy(), model.b.copy()
+    y0, dy, ey = model.y0.copy(), model.dy.copy(), model.ey.copy()
+    if model.subs:
+        s = model.subs[0]
+        ps = s.dq @ xs + s.eq @ u
+        r = ModelRunner(model, 1, lib=lib, device=device)
+        z, conv, _ = r.solve(ps[None, :])
+        if not conv.all():
+            raise ValueError(f"Cannot linearize because no solution found at p={ps}")
+        z = z[0]
+        q = s.q0 + s.pexp @ ps + s.fq @ z
+        _, jq = eval_table(s.table, q.tolist(), s.nn, s.nq)
+        jq = np.asarray(jq)
+        dzdp = -np.linalg.solve(jq @ s.fq, jq @ s.pexp)          # get_extrapolation_jacobian
+        x0 += model.c @ (z - dzdp @ ps)
+        a += model.c @ dzdp @ s.dq
+        b += model.c @ dzdp @ s.eq
+        y0 += model.fy @ (z - dzdp @ ps)
+        dy += model.fy @ dzdp @ s.dq
+        ey += model.fy @ dzdp @ s.eq
+    nx, nu, ny = model.nx, model.nu, model.ny
+    d = dict(nx=nx, nu=nu, ny=ny, nsub=0, nns=[], nqs=[], nps=[], a=a, b=b, c=np.zeros((nx, 0)), x0=x0,
+             dy=dy, ey=ey, fy=np.zeros((ny, 0)), y0=y0, pexps=[], dqs=[], eqs=[], fqprevs=[], fqs=[], q0s=[],
+             init_zs=[], tables=[])
+    return DiscreteModel(solver=model.solver, _data=d)

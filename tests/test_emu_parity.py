@@ -271,3 +271,23 @@ def test_emulated_decomposed_nonlinearity(emu_lib):
     ms = DiscreteModel(circuits.series_diodes_circuit(), Fraction(1))    # test/runtests.jl:286-291
     y = emu_runner(emu_lib, ms, 1).run(np.array([[2.0], [1.0]]))
     np.testing.assert_allclose(y[:, 0], 1e-12 * (np.exp(1 / 25e-3) - 1), rtol=1.5e-8)
+
+
+def test_emulated_linearize(emu_lib):
+    """linearization_error! (test/runtests.jl:673-682) on the chirp the reference uses (shortened):
+    birdie < 1e-7 at amplitude 1e-4 (:730), superover < 1e-4 (:749), diode clipper at 1e-3."""
+    from acme_jl_amd.analysis import linearize, steadystate_
+    from acme_jl_amd.runner import ModelRunner
+    N = 3000
+    for name, amp, bound in (("diodeclipper", 1e-3, 1e-6), ("birdie_fixed", 1e-4, 1e-7), ("superover_fixed", 1e-4, 1e-4)):
+        m = load(name)
+        lin = linearize(m, lib=emu_lib)
+        assert not lin.subs and lin.a.shape == m.a.shape
+        u = (amp * np.sin(np.pi / 2 * np.arange(N + 1) ** 2 / 50000))[None, None, :]
+        r = ModelRunner(m, 1, lib=emu_lib)
+        steadystate_(r)
+        rl = ModelRunner(lin, 1, lib=emu_lib)
+        steadystate_(rl)
+        err = np.abs(r.run(u) - rl.run(u)).max()
+        print(name, "linearization error", err)
+        assert err < bound
