@@ -39,7 +39,10 @@ enum RowKind { RK_NONE = 0, RK_DIODE = 1, RK_BJT = 2, RK_POT = 3, RK_MOSFET = 4,
 // row flags
 enum RowFlags { RF_EARLY = 1, RF_KNEE = 2, RF_ILE = 4, RF_ILC = 8, RF_ETAEL = 16, RF_ETACL = 32 };
 
-enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1 };
+enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1, SOLVER_CACHING_HOMOTOPY = 2 };
+// CachingSolver on the GPU: per instance and sub-problem the last CACHE stored solutions (p, z),
+// first in first out, in LDS (the reference keeps every stored solution in a k-d tree)
+constexpr int CACHE = 8;
 
 struct Dims {
     int nn, nq, np, nx, nu, ny;
@@ -104,6 +107,7 @@ struct KArgs {
     double *y;               // [n_inst][T][ny_io]
     double *state;           // [n_inst][nx + np + nn] : x | last_p | last_z
     long long *report;       // [n_inst][RW_WORDS]
+    double *cache;           // [n_inst][nsub_shape][cache_doubles]: the solution caches between launches
     int *roworder;           // [n_inst][nsub_shape][16]: lane -> residual row assignment the lanes had
                              // adopted when the previous launch ended (identity = the host hint); kept
                              // so that a run split over several launches repeats the one-launch arithmetic

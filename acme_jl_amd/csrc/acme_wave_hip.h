@@ -74,6 +74,22 @@ ACME_DEV double allmax16(double v) {
     return v;
 }
 
+// min / sum over the 16 lanes of each row, result in every lane
+ACME_DEV double allmin16(double v) {
+    v = fmin(v, ror16<8>(v));
+    v = fmin(v, ror16<4>(v));
+    v = fmin(v, ror16<2>(v));
+    v = fmin(v, ror16<1>(v));
+    return v;
+}
+ACME_DEV double allsum16(double v) {
+    v += ror16<8>(v);
+    v += ror16<4>(v);
+    v += ror16<2>(v);
+    v += ror16<1>(v);
+    return v;
+}
+
 // arbitrary gather inside a row: value of lane (row base + src) -- ds_bpermute_b32
 ACME_DEV int shfl16(int v, int src) {
     int lane = (int)(threadIdx.x & 63);

@@ -58,10 +58,12 @@ class SubProblem:
 class DiscreteModel:
     """``DiscreteModel(circ, t, Solver; decompose_nonlinearity=true)`` (src/ACME.jl:150).
 
-    ``solver`` defaults to ``HomotopySolver{SimpleSolver}``: the reference's default
-    additionally wraps a ``CachingSolver`` whose per-stream, unboundedly growing k-d tree
-    only changes Newton's start point; it is deliberately not reproduced on the GPU
-    (converged results agree within the solver tolerance).
+    ``solver`` defaults to ``HomotopySolver{SimpleSolver}``.  The reference's default additionally
+    wraps a ``CachingSolver`` (a per-stream, unboundedly growing k-d tree of stored solutions that
+    only changes Newton's start point): ``solver=CachingHomotopySolver`` selects the GPU's
+    bounded variant of it (the last 8 stored solutions per instance, same lookup and storing
+    rules; converged results agree within the solver tolerance, iteration counts follow the
+    oracle's bounded variant).
     """
 
     def __init__(self, circ=None, t=None, solver=HomotopySolver, decompose_nonlinearity=True,

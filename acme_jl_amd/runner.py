@@ -195,11 +195,6 @@ class ModelRunner:
                  lib=None):
         if not isinstance(model, DiscreteModel):
             raise TypeError("model must be a DiscreteModel")
-        if model.solver == CachingHomotopySolver:
-            raise AcmeError(
-                "CachingSolver is not available on the GPU path (per-stream unbounded k-d tree, "
-                "only changes Newton's start point); construct the model with "
-                "solver=HomotopySolver")
         self.lib = lib or default_library()
         if self.lib.device_count() <= 0:
             raise AcmeError("no HIP device available; acme_jl_amd has no CPU fallback")

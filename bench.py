@@ -126,14 +126,16 @@ def algorithmic_flops(model, iters_per_sample):
 
 
 def _cpu_worker(args):
-    fixture, rows, T = args
-    from acme_jl_amd.model import DiscreteModel
+    fixture, rows, T, solver = args
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
     from oracle.refpy import RefRunner
-    m = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"))
+    m = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
     t0 = time.perf_counter()
     iters = 0
     for u in rows:
         r = RefRunner(m)
+        if solver == CachingHomotopySolver:
+            r.set_cache_limit(8)      # the GPU's bounded store: same algorithm on both sides
         r.run(u)
         iters += r.report.iters_total
     return time.perf_counter() - t0, iters
@@ -174,7 +176,7 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=12):
             if pots is not None:
                 u[1:] = pots[i][:, None]
             rows.append(u)
-        jobs.append((fixture, rows, T_cpu))
+        jobs.append((fixture, rows, T_cpu, model.solver))
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, jobs, chunksize=1)
     slowest = max(r[0] for r in res)
@@ -200,6 +202,9 @@ def main():
                          "config 2; superover_montecarlo = config 4 (per-instance model blocks)")
     ap.add_argument("--instances", type=int, default=None, help="instances per GPU")
     ap.add_argument("--samples", type=int, default=FS, help="samples per step")
+    ap.add_argument("--solver", default="caching", choices=["caching", "homotopy", "simple"],
+                    help="caching = HomotopySolver{CachingSolver{SimpleSolver}}, the reference's default stack "
+                         "(GPU: bounded 8-entry store per instance); homotopy = HomotopySolver{SimpleSolver}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=None)
     args = ap.parse_args()
@@ -229,7 +234,9 @@ def main():
     T = args.samples
     fixture, pots, amp = grid_inputs(args.workload, rank, world, n_per_gpu, T)
     # rank 0 owns the model block; everyone else receives it over RCCL (xGMI)
-    model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json")) \
+    from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver, SimpleSolver
+    solver = {"caching": CachingHomotopySolver, "homotopy": HomotopySolver, "simple": SimpleSolver}[args.solver]
+    model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver) \
         if rank == 0 else None
     model = broadcast_model(model, src=0, device=dev) if world > 1 else model
 
@@ -239,6 +246,7 @@ def main():
         batch = montecarlo_models(rank, n_per_gpu)
         setup["derive_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
+        batch.solver = solver
         model = batch.model(0)
         runner = ModelRunner(model, n_per_gpu, device=local_rank, models=batch)
         setup["upload_s"] = time.perf_counter() - t0

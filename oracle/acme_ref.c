@@ -369,6 +369,7 @@ typedef struct {
     /* CachingSolver (src/solvers.jl:319-339) */
     double *ps, *zs;
     int num_ps, cap_ps;
+    int cache_limit, cache_head; /* > 0: bounded FIFO variant (the GPU's solution cache), 0: the reference's unbounded store */
 } ref_solver;
 
 /* set_p closure (src/ACME.jl:237-243): pfull <- q0 + pexp*p */
@@ -508,7 +509,12 @@ static const double *caching_solve(ref_solver *s, const double *p) {
     }
     if (idx >= 0) set_origin(s, s->ps + (size_t)idx * np, s->zs + (size_t)idx * nn);
     const double *z = simple_solve(s, p);
-    if (s->iters > 5 && simple_hasconverged(s)) {
+    if (s->iters > 5 && simple_hasconverged(s) && s->cache_limit > 0 && s->num_ps == s->cache_limit) {
+        /* bounded variant: overwrite the oldest entry */
+        memcpy(s->ps + (size_t)s->cache_head * np, p, sizeof(double) * (size_t)np);
+        memcpy(s->zs + (size_t)s->cache_head * nn, z, sizeof(double) * (size_t)nn);
+        s->cache_head = (s->cache_head + 1) % s->cache_limit;
+    } else if (s->iters > 5 && simple_hasconverged(s)) {
         if (s->num_ps == s->cap_ps) {
             s->cap_ps = 2 * (s->num_ps + 1);
             s->ps = (double *)realloc(s->ps, sizeof(double) * (size_t)np * s->cap_ps + 8);
@@ -632,6 +638,15 @@ void acme_ref_set_resabstol(acme_ref_runner *r, double tol) {
 
 void acme_ref_set_maxiter(acme_ref_runner *r, int maxiter) {
     for (int i = 0; i < r->m->nsub; ++i) r->solvers[i].maxiter = maxiter;
+}
+
+/* CachingSolver with a bounded FIFO store of `limit` solutions (0 = unbounded, the reference):
+ * the variant the GPU kernel implements, for iteration-count parity tests.  Call before running. */
+void acme_ref_set_cache_limit(acme_ref_runner *r, int limit) {
+    for (int i = 0; i < r->m->nsub; ++i) {
+        r->solvers[i].cache_limit = limit;
+        r->solvers[i].cache_head = 0;
+    }
 }
 
 static const double *any_solve(acme_ref_runner *r, int idx, const double *p, int *iters) {

@@ -78,6 +78,8 @@ acme_ref_runner *acme_ref_runner_create(const acme_ref_model *m, int solver_kind
 void acme_ref_runner_destroy(acme_ref_runner *r);
 void acme_ref_set_resabstol(acme_ref_runner *r, double tol);   /* src/solvers.jl:181 */
 void acme_ref_set_maxiter(acme_ref_runner *r, int maxiter);    /* src/solvers.jl:207 */
+/* CachingSolver with a bounded FIFO store (0 = unbounded = the reference); the GPU's variant */
+void acme_ref_set_cache_limit(acme_ref_runner *r, int limit);
 
 /* run!(runner, y, u) (src/ACME.jl:650-664): u is nu x T, y is ny x T, column-major.
  * Returns 0, or 1 if the reference would have thrown "got non-finite result" (then

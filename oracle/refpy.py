@@ -50,6 +50,7 @@ def lib():
         L.acme_ref_runner_destroy.argtypes = [vp]
         L.acme_ref_set_resabstol.argtypes = [vp, C.c_double]
         L.acme_ref_set_maxiter.argtypes = [vp, C.c_int]
+        L.acme_ref_set_cache_limit.argtypes = [vp, C.c_int]
         L.acme_ref_run.restype = C.c_int
         L.acme_ref_run.argtypes = [vp, dp, dp, C.c_longlong, C.POINTER(Report)]
         L.acme_ref_get_x.argtypes = [vp, dp]
@@ -126,6 +127,10 @@ class RefRunner:
 
     def set_maxiter(self, n):
         lib().acme_ref_set_maxiter(self.h, int(n))
+
+    def set_cache_limit(self, n):
+        """CachingSolver with a FIFO store bounded to ``n`` solutions (0: unbounded, the reference)."""
+        lib().acme_ref_set_cache_limit(self.h, int(n))
 
     def run(self, u, raise_on_nonfinite=True):
         m = self.model

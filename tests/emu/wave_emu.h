@@ -187,6 +187,20 @@ ACME_DEV double allmax16(double v) {
     v = fmax(v, ror16<1>(v));
     return v;
 }
+ACME_DEV double allmin16(double v) {
+    v = fmin(v, ror16<8>(v));
+    v = fmin(v, ror16<4>(v));
+    v = fmin(v, ror16<2>(v));
+    v = fmin(v, ror16<1>(v));
+    return v;
+}
+ACME_DEV double allsum16(double v) {
+    v += ror16<8>(v);
+    v += ror16<4>(v);
+    v += ror16<2>(v);
+    v += ror16<1>(v);
+    return v;
+}
 ACME_DEV int shfl16(int v, int src) {
     int lane = tid() & 63;
     return (int)(int64_t)emu::exchange((uint64_t)(int64_t)v, (lane & ~15) + (src & 15), 400);

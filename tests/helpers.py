@@ -60,12 +60,16 @@ def sweep_inputs(name, N, T, seed=0):
     raise KeyError(name)
 
 
-def oracle_run(model, u, solver=None):
-    """y [N, ny, T] from the CPU oracle, one fresh runner per instance."""
+def oracle_run(model, u, solver=None, cache_limit=None):
+    """y [N, ny, T] from the CPU oracle, one fresh runner per instance.  ``cache_limit``: bounded
+    FIFO store for the CachingSolver stack (8 = what the GPU implements; None = the reference's
+    unbounded store)."""
     from oracle.refpy import RefRunner
     ys, its = [], []
     for i in range(u.shape[0]):
         r = RefRunner(model, solver)
+        if cache_limit is not None:
+            r.set_cache_limit(cache_limit)
         ys.append(r.run(u[i]))
         its.append(r.report.iters_total)
     return np.stack(ys), np.array(its)

@@ -291,3 +291,39 @@ def test_emulated_linearize(emu_lib):
         err = np.abs(r.run(u) - rl.run(u)).max()
         print(name, "linearization error", err)
         assert err < bound
+
+
+def test_emulated_caching_solver(emu_lib):
+    """HomotopySolver{CachingSolver{SimpleSolver}} with the GPU's bounded store (8 solutions, FIFO):
+    same outputs AND the same iteration counts as the oracle's bounded variant; far fewer
+    iterations than without the cache; results of the two solver stacks agree within the solver
+    tolerance."""
+    from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    for name, N, T in (("superover_var", 4, 450), ("birdie_var", 3, 600), ("diodeclipper", 3, 300)):
+        m = load(name, CachingHomotopySolver)
+        u = sweep_inputs(name, N, T)
+        r = ModelRunner(m, N, lib=emu_lib)
+        y = r.run(u)
+        yref, its = oracle_run(m, u, cache_limit=8)
+        assert_close(y, yref)
+        # same algorithm, same Newton paths: the counts agree unless a rounding-level flip of a
+        # convergence test or of a nearest-entry decision sends one side down another path
+        assert np.abs(r.report_arrays()["iters_total"] - its).max() <= max(3, 0.1 * its.max())
+        y2, its2 = oracle_run(m, u, solver=HomotopySolver)
+        assert_close(y, y2, rtol=5e-6)    # two legal solver stacks: each within tol/g_min of the root
+        if name == "superover_var":
+            assert its.sum() < 0.8 * its2.sum()
+
+
+def test_emulated_caching_split_run_and_solve(emu_lib):
+    """The solution caches persist across launches (a split run is bit-identical) and serve the
+    solver plugin entry point as well."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    m = load("superover_fixed", CachingHomotopySolver)
+    u = sweep_inputs("superover_fixed", 4, 300)
+    y1 = ModelRunner(m, 4, lib=emu_lib).run(u)
+    r = ModelRunner(m, 4, lib=emu_lib)
+    y2 = np.concatenate([r.run(u[:, :, :131]), r.run(u[:, :, 131:])], axis=2)
+    assert np.array_equal(y1, y2)

@@ -349,3 +349,39 @@ def test_linearize(hip_lib):
         err = np.abs(r.run(u) - rl.run(u)).max()
         print(name, "linearization error", err)
         assert err < bound
+
+
+def test_caching_solver(hip_lib):
+    """solver = HomotopySolver{CachingSolver{SimpleSolver}} (the reference's default stack) with the
+    GPU's bounded store: outputs and iteration counts against the oracle's bounded variant, the
+    other solver stack within the solver tolerance, split runs bit-identical, and the bench grid
+    at full width through block-split / permutation invariance."""
+    import torch
+    import bench
+    from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
+    for name, N, T in (("superover_var", 24, 1500), ("birdie_var_176k", 10, 3000), ("diodeclipper", 20, 1000)):
+        m = load(name, CachingHomotopySolver)
+        u = sweep_inputs(name, N, T)
+        r = runner(hip_lib, m, N)
+        y = r.run(u)
+        yref, its = oracle_run(m, u, cache_limit=8)
+        assert_close(y, yref)
+        ra = r.report_arrays()
+        # same algorithm, same Newton paths: the counts agree unless a rounding-level flip of a
+        # convergence test or of a nearest-entry decision sends one side down another path
+        assert np.abs(ra["iters_total"] - its).max() <= max(3, 0.1 * its.max())
+        assert abs(int(ra["iters_total"].sum()) - int(its.sum())) <= 0.02 * its.sum()
+        y2, its2 = oracle_run(m, u, solver=HomotopySolver)
+        assert_close(y, y2, rtol=5e-6)    # two legal solver stacks: each within tol/g_min of the root
+        print(name, "iterations with cache", its.sum(), "without", its2.sum())
+    m = load("superover_var", CachingHomotopySolver)
+    N, T = 8192, 1200
+    _, pots, amp = bench.grid_inputs("superover_grid", 0, 1, N, T)
+    u = bench.make_u(torch, torch.device("cuda"), m, pots, amp, N, T)
+    y1 = runner(hip_lib, m, N).run_torch(u)
+    r2 = runner(hip_lib, m, N)
+    y2 = torch.cat([r2.run_torch(u[:, a:b].contiguous()) for a, b in ((0, 333), (333, T))], dim=1)
+    assert torch.equal(y1, y2)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).cuda()
+    y3 = runner(hip_lib, m, N).run_torch(u[perm].contiguous())
+    assert torch.equal(y1[perm], y3)
