@@ -764,20 +764,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         rowids[s] = rowid;
     };
 
-    // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196): the factors and Jp
-    // at the origin are recomputed from (p, z), so only (p, z) has to persist in HBM.
-    sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
-        constexpr int s = decltype(sc)::value;
-        if (NN > 0 && s < nsub) {
-            enter_sub(sc);
-            set_p(lp);
-            z = lz;
-            bool f0, k0, s0;
-            double d0;
-            linearize(z, false, true, f0, k0, s0, d0);
-            leave_sub(sc);
-        }
-    });
+    // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196): the factors and Jp at the
+    // origin are recomputed from (p, z), so only (p, z) has to persist in HBM.  That happens
+    // lazily, before the first base solve of each sub-problem (`fresh`), through the same code as a
+    // change of origin on a solution-cache hit (cached_solve).
+    bool fresh[NSUB > 0 ? NSUB : 1];
+    sfor<0, NSUB>([&](auto sc) ACME_LAMBDA { fresh[decltype(sc)::value] = true; });
     if (S::NSUB == 1) enter_sub(std::integral_constant<int, 0>{});   // stays entered for the whole launch
 
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
@@ -826,9 +818,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // keeps all of them in a k-d tree; on the bench grid 8 entries give 3.56 Newton iterations per
     // sample against 3.48 unbounded and 6.36 without a cache).  Lane e < CACHE owns entry e.
     const bool caching = A.solver == SOLVER_CACHING_HOMOTOPY;
-    auto cached_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
+    auto cached_solve = [&](double target, bool need, bool first, int &its) ACME_LAMBDA -> bool {
         double *cp = cch, *cz = cch + NP * CACHE;
         int *meta = reinterpret_cast<int *>(cch + (NP + NN) * CACHE);   // count, head
+        bool reorig = first;        // (lp, lz) not linearised yet: launch start, or new origin below
         if (caching) {
             const int count = meta[0];
             const double dl = (lig < NP) ? target - lp : 0.0;
@@ -849,11 +842,14 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 const double cpl = cp[(lig < NP ? lig : 0) * CACHE + e], czl = cz[(lig < NN ? lig : 0) * CACHE + e];
                 lp = hit ? cpl : lp;
                 lz = hit ? czl : lz;
-                set_p(lp);
-                bool f0, k0, s0;
-                double d0;
-                linearize(hit ? lz : z, false, hit, f0, k0, s0, d0);
             }
+            reorig = reorig || hit;
+        }
+        if (wv::ballot(reorig)) {
+            set_p(lp);
+            bool f0, k0, s0;
+            double d0;
+            linearize(reorig ? lz : z, false, reorig, f0, k0, s0, d0);
         }
         const bool c = base_solve(target, need, its);
         if (caching) {
@@ -963,7 +959,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 ACME_T(TB_PRE);
                 while (wv::ballot(need)) {
                     int its;
-                    bool c = cached_solve(target, need, its);
+                    bool c = cached_solve(target, need, fresh[s], its);
+                    fresh[s] = false;
                     ACME_DBG("hom step lane %d need %d mode %d ha %.17g hbest %.17g conv %d its %d", lane, (int)need, mode, ha, hbest, (int)c, its);
                     its_sample += need ? its : 0;
                     conv = need ? c : conv;

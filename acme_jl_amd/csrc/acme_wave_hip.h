@@ -129,7 +129,11 @@ ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 ACME_DEV double keep(double v) { asm volatile("" : "+v"(v)); return v; }
 // wave-uniform integer the optimiser must not reason about (stops it from cloning a big loop
 // body per value of a small state variable)
-ACME_DEV int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+ACME_DEV int opaque(int v) {
+    v = __builtin_amdgcn_readfirstlane(v);   // uniform by construction; tells the compiler so
+    asm volatile("" : "+s"(v));
+    return v;
+}
 // wave mask pinned in a scalar register pair here and now: keeps an OR-chain of ballots
 // sequential (left to itself the optimiser gathers all terms first and spills them)
 ACME_DEV unsigned long long pin(unsigned long long m) { asm volatile("" : "+s"(m)); return m; }
