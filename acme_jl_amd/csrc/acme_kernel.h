@@ -888,10 +888,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     const bool solve_mode = A.p_in != nullptr;
     const long long T = solve_mode ? 1 : A.T;
     const int nu_io = A.nu_io, ny_io = A.ny_io;
-    // u tile: fetched for chunk 0 before the loop and for chunk c+1 during the LAST sample of
-    // chunk c: the loads are issued right after that sample's Newton solve, the tile is
-    // overwritten after its y/x update (the last readers of the old tile) -- the ~1 us of HBM
-    // latency hides behind that update and no staging register lives across the solver loop.
+    // u tile: fetched for chunk 0 before the loop and for chunk c+1 at the end of the LAST sample of
+    // chunk c (after its y/x update, the last readers of the old tile).  The ~1 us of HBM latency is
+    // exposed once per 16 samples (< 0.5 % of their run time); issuing the loads earlier kept the
+    // staging registers alive across the update and cost more in spill traffic than it hid.
     // (Global pointers are recomputed here, once per 16 samples, for the same reason.)
     double upre[S::NUR];
     auto fetch_u = [&](long long n0) ACME_LAMBDA {
@@ -1019,7 +1019,6 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             });
             if (solve_mode) continue;
             const bool refill = NU > 0 && m == cnt - 1 && n0 + CHUNK < T;
-            if (refill) fetch_u(n0 + CHUNK);
             const bool live = !dead;
             wv::sched_fence();
             // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
@@ -1082,7 +1081,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     x[s] = sel(live, xn[s], x[s]);
                 });
             }
-            if (refill) stage_u();
+            if (refill) {     // next u tile: this sample's y/x update was the last reader of the old one
+                fetch_u(n0 + CHUNK);
+                stage_u();
+            }
         }
         // flush the y tile, coalesced
         if (NY > 0 && !solve_mode) {
