@@ -58,7 +58,8 @@ struct Dims {
 // The lane that evaluates row r then reads consecutive addresses for fixed (t, j): no
 // indirection and no LDS bank conflicts (the plain fq[tc + j*nq] form was ~39 % conflicts).
 struct Layout {
-    int a, b, c, x0, dy, ey, fy, y0;            // shared, absolute offsets
+    int a, b, c, x0, dy, ey, fy, y0;            // shared, absolute offsets (dy.. = a.. + nx: extra rows)
+    int ld;                                     // leading dimension of those matrices: nx + ny
     int sub0, sub_stride;                       // first sub-problem block, distance to the next
     int dq, eq, fqprev, pexpr, fqr, q0r;        // offsets relative to a sub-problem block
     int total;
@@ -68,15 +69,19 @@ ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int
     Layout L{};
     (void)nq;
     const int nz = nsub * nn;
+    // [a; dy], [b; ey], [c; fy], [x0; y0] are stored as single matrices with nx + ny rows (leading
+    // dimension ld): when nx + ny <= 16 one pass over 16 lanes yields the new state AND the output
+    const int ld = nx + ny;
     int o = 0;
-    L.a = o;    o += nx * nx;
-    L.b = o;    o += nx * nu;
-    L.c = o;    o += nx * nz;
-    L.x0 = o;   o += nx;
-    L.dy = o;   o += ny * nx;
-    L.ey = o;   o += ny * nu;
-    L.fy = o;   o += ny * nz;
-    L.y0 = o;   o += ny;
+    L.ld = ld;
+    L.a = o;    o += ld * nx;
+    L.b = o;    o += ld * nu;
+    L.c = o;    o += ld * nz;
+    L.x0 = o;   o += ld;
+    L.dy = L.a + nx;
+    L.ey = L.b + nx;
+    L.fy = L.c + nx;
+    L.y0 = L.x0 + nx;
     L.sub0 = (o + 1) & ~1;
     int r = 0;
     L.dq = r;     r += np * nx;

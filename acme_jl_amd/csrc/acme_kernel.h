@@ -1021,22 +1021,47 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             const bool refill = NU > 0 && m == cnt - 1 && n0 + CHUNK < T;
             const bool live = !dead;
             wv::sched_fence();
-            // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
-            if (NY > 0) {
-                double yy = M[L.y0 + lig];
+            constexpr int LD = NX + NY;
+            if constexpr (NX + NY <= GROUP && NX > 0) {
+                // y = y0 + dy*x + ey*u + fy*z with the OLD x (src/ACME.jl:699-706) and
+                // x = x0 + a*x + b*u + c*z (:708-714) in ONE pass: lanes < NX hold the rows of
+                // [a b c x0], lanes NX .. NX+NY-1 the rows of [dy ey fy y0] (same operations per row
+                // as two separate passes, half the instructions and LDS reads)
+                double acc = M[L.x0 + lig];
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    yy = fma(M[L.dy + j * NY + lig], wv::bcast16<j % GROUP>(x[j / GROUP]), yy);
+                    acc = fma(M[L.a + j * LD + lig], wv::bcast16<j>(x[0]), acc);
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    yy = fma(M[L.ey + k * NY + lig], ubuf[m * NU + k], yy);
+                    acc = fma(M[L.b + k * LD + lig], ubuf[m * NU + k], acc);
                 });
                 sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
                     constexpr int s = decltype(sc)::value;
                     sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                         constexpr int j = decltype(jc)::value;
-                        yy = fma(M[L.fy + (s * NN + j) * NY + lig], wv::bcast16<j>(zs[s]), yy);
+                        acc = fma(M[L.c + (s * NN + j) * LD + lig], wv::bcast16<j>(zs[s]), acc);
+                    });
+                });
+                if (NY > 0 && lig >= NX && lig < NX + NY) ybuf[m * NY + lig - NX] = live ? acc : (double)NAN;
+                x[0] = sel(live && lig < NX, acc, x[0]);
+            } else {
+            // y = y0 + dy*x + ey*u + fy*z  with the OLD x  (src/ACME.jl:699-706)
+            if (NY > 0) {
+                double yy = M[L.y0 + lig];
+                sfor<0, NX>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    yy = fma(M[L.dy + j * LD + lig], wv::bcast16<j % GROUP>(x[j / GROUP]), yy);
+                });
+                sfor<0, NU>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = decltype(kc)::value;
+                    yy = fma(M[L.ey + k * LD + lig], ubuf[m * NU + k], yy);
+                });
+                sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
+                    constexpr int s = decltype(sc)::value;
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        yy = fma(M[L.fy + (s * NN + j) * LD + lig], wv::bcast16<j>(zs[s]), yy);
                     });
                 });
                 if (lig < NY) ybuf[m * NY + lig] = live ? yy : (double)NAN;
@@ -1054,7 +1079,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
                     sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
                         constexpr int s = decltype(sc)::value;
-                        xn[s] = fma(M[L.a + j * NX + s * GROUP + lig], xj, xn[s]);
+                        xn[s] = fma(M[L.a + j * LD + s * GROUP + lig], xj, xn[s]);
                     });
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
@@ -1062,7 +1087,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     double uk = ubuf[m * NU + k];
                     sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
                         constexpr int s = decltype(sc)::value;
-                        xn[s] = fma(M[L.b + k * NX + s * GROUP + lig], uk, xn[s]);
+                        xn[s] = fma(M[L.b + k * LD + s * GROUP + lig], uk, xn[s]);
                     });
                 });
                 sfor<0, S::NSUB>([&](auto pc) ACME_LAMBDA {
@@ -1072,7 +1097,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                         double zj = wv::bcast16<j>(zs[sp]);
                         sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
                             constexpr int s = decltype(sc)::value;
-                            xn[s] = fma(M[L.c + (sp * NN + j) * NX + s * GROUP + lig], zj, xn[s]);
+                            xn[s] = fma(M[L.c + (sp * NN + j) * LD + s * GROUP + lig], zj, xn[s]);
                         });
                     });
                 });
@@ -1080,6 +1105,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     constexpr int s = decltype(sc)::value;
                     x[s] = sel(live, xn[s], x[s]);
                 });
+            }
             }
             if (refill) {     // next u tile: this sample's y/x update was the last reader of the old one
                 fetch_u(n0 + CHUNK);

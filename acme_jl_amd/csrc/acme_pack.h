@@ -277,12 +277,12 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     const int NSUBr = S.nsub > 0 ? S.nsub : 1;
     const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny, NT, NSUBr);
     P.image.assign(L.total, 0.0);
-    put(P.image, L.a, S.nx, m.a, d.nx, d.nx);
-    put(P.image, L.b, S.nx, m.b, d.nx, d.nu);
-    put(P.image, L.x0, S.nx, m.x0, d.nx, 1);
-    put(P.image, L.dy, S.ny, m.dy, d.ny, d.nx);
-    put(P.image, L.ey, S.ny, m.ey, d.ny, d.nu);
-    put(P.image, L.y0, S.ny, m.y0, d.ny, 1);
+    put(P.image, L.a, L.ld, m.a, d.nx, d.nx);
+    put(P.image, L.b, L.ld, m.b, d.nx, d.nu);
+    put(P.image, L.x0, L.ld, m.x0, d.nx, 1);
+    put(P.image, L.dy, L.ld, m.dy, d.ny, d.nx);
+    put(P.image, L.ey, L.ld, m.ey, d.ny, d.nu);
+    put(P.image, L.y0, L.ld, m.y0, d.ny, 1);
     P.rowc.assign((size_t)NSUBr * ROWC * GROUP, 0.0);
     P.rowi.assign((size_t)NSUBr * ROWI * GROUP, 0);
     P.init_state.assign((size_t)S.nx + (size_t)NSUBr * (S.np + S.nn), 0.0);
@@ -295,8 +295,8 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         const int base = L.sub0 + (int)k * L.sub_stride;
         // c and fy: this sub-problem's z columns go to padded columns k*NN ...
         for (int j = 0; j < s->nn; ++j) {
-            for (int i = 0; i < d.nx; ++i) P.image[L.c + ((size_t)k * S.nn + j) * S.nx + i] = m.c[(size_t)(zoff[k] + j) * d.nx + i];
-            for (int i = 0; i < d.ny; ++i) P.image[L.fy + ((size_t)k * S.nn + j) * S.ny + i] = m.fy[(size_t)(zoff[k] + j) * d.ny + i];
+            for (int i = 0; i < d.nx; ++i) P.image[L.c + ((size_t)k * S.nn + j) * L.ld + i] = m.c[(size_t)(zoff[k] + j) * d.nx + i];
+            for (int i = 0; i < d.ny; ++i) P.image[L.fy + ((size_t)k * S.nn + j) * L.ld + i] = m.fy[(size_t)(zoff[k] + j) * d.ny + i];
         }
         put(P.image, base + L.dq, S.np, s->dq, s->np, d.nx);
         put(P.image, base + L.eq, S.np, s->eq, s->np, d.nu);

@@ -23,7 +23,9 @@ def main(T=2205, n=8192):
     dev = torch.device("cuda:0")
     fixture, pots, amp = bench.grid_inputs("superover_grid", 0, 1, n, T)
     from acme_jl_amd.model import DiscreteModel
-    model = DiscreteModel.load(os.path.join(bench.ROOT, "tests", "golden", fixture + ".json"))
+    from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
+    solver = HomotopySolver if os.environ.get("ACME_PROBE_SOLVER") == "homotopy" else CachingHomotopySolver
+    model = DiscreteModel.load(os.path.join(bench.ROOT, "tests", "golden", fixture + ".json"), solver=solver)
     u = bench.make_u(torch, dev, model, pots, amp, n, T)
     r = R.ModelRunner(model, n)
     y = r.run_torch(u)
