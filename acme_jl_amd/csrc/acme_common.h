@@ -126,7 +126,6 @@ struct KArgs {
     int nterms;              // max non-zeros per Jq row (2..4)
     int has_bjt;             // any BJT row -> second exp needed
     int rare_kinds;          // any MOSFET/MACAK/JA row
-    int prof[4];             // only read by ACME_PROFILE_PIECES builds (tools/profile_pieces.py)
     // solver-plugin mode (acme_batch_solve): if p_in != nullptr the launch performs ONE
     // solve(solver, p) per instance instead of running samples: p comes from p_in, the
     // solution / hasconverged / needediterations go to z_out / conv_out / iters_out, x is

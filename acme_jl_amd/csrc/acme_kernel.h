@@ -568,9 +568,6 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
 #define ACME_T2(bucket) do { } while (0)
 #endif
 
-#ifdef ACME_PROFILE_PIECES
-    double prof_sink = 0.0;
-#endif
     // ---- helpers ------------------------------------------------------------------------
     // pfull <- q0 + pexp*p   (set_p closure, src/ACME.jl:237-243), only the entries this
     // lane's row needs
