@@ -318,7 +318,11 @@ def main():
                 if args.workload == "superover_montecarlo" else
                 f"examples/diodeclipper.jl, {n_per_gpu}-instance amplitude sweep 10mV..10V per GPU",
                 "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": FS,
-                "solver": model.solver, "parallelism": f"instance-sharded x{world}",
+                "solver": model.solver,
+                "solver_note": "caching = the reference's default stack; GPU and CPU oracle keep the last 8 stored "
+                               "solutions per instance (reference: unbounded k-d tree), same lookup/store rules; "
+                               "--solver homotopy runs HomotopySolver{SimpleSolver}",
+                "parallelism": f"instance-sharded x{world}",
                 "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,
                 "n_warn": n_warn, "n_nonfinite_instances": n_dead, "y_abs_sum_rank0": checksum,
                 **({"host_setup": setup} if setup else {}),
