@@ -1,5 +1,14 @@
-import sys, time, numpy as np
-sys.path.insert(0,'tests'); sys.path.insert(0,'.')
+"""Long-run randomized parity sweep on the GPU (developer script, run through gpurun):
+48 random superover instances x 44 100 samples against the oracle, for both solver stacks.
+Lives under tests/ because it uses the oracle.   python tests/parity_sweep.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helpers import load, oracle_run, assert_close
 from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
 from acme_jl_amd.runner import ModelRunner
