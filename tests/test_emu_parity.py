@@ -316,6 +316,32 @@ def test_emulated_caching_solver(emu_lib):
             assert its.sum() < 0.8 * its2.sum()
 
 
+def test_emulated_caching_decomposed_and_per_instance(emu_lib):
+    """One solution cache per sub-problem (the reference has one CachingSolver per sub-problem),
+    and per-instance model blocks start from their own initial cached point."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    m = _simplified_superover(False)
+    m.solver = CachingHomotopySolver
+    assert len(m.subs) == 3
+    u = sweep_inputs("superover_fixed", 3, 300)
+    r = ModelRunner(m, 3, lib=emu_lib)
+    yref, its = oracle_run(m, u, cache_limit=8)
+    assert_close(r.run(u), yref)
+    assert np.abs(r.report_arrays()["iters_total"] - its).max() <= max(3, 0.1 * its.max())
+    rng = np.random.Generator(np.random.PCG64(7))
+    models = [DiscreteModel(examples.superover(1.0, 1.0, 1.0, value=lambda n, v: v * (1 + 0.05 * rng.uniform(-1, 1))),
+                            Fraction(1, 44100), solver=CachingHomotopySolver) for _ in range(3)]
+    from helpers import sine
+    u = np.tile(0.7 * sine(250)[None, None, :], (3, 1, 1))
+    y = ModelRunner(models[0], 3, models=models, lib=emu_lib).run(u)
+    for k in range(3):
+        yref, _ = oracle_run(models[k], u[k:k + 1], cache_limit=8)
+        assert_close(y[k:k + 1], yref)
+
+
 def test_emulated_caching_split_run_and_solve(emu_lib):
     """The solution caches persist across launches (a split run is bit-identical) and serve the
     solver plugin entry point as well."""
