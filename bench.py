@@ -154,7 +154,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=12):
+def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24):
     """Time the CPU oracle on a bounded, evenly spread sample of the same workload: one
     worker process per host core, `per_core` instance streams of T_cpu samples each (the
     reference's DiscreteModel is single-threaded and non-re-entrant, so independent per-core
