@@ -994,10 +994,10 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     }
                 } else {
                     // convergence policy of step! (src/ACME.jl:688-694)
-                    unsigned long long nf = wv::ballot(lig < NN && !(z * 0.0 == 0.0));
-                    bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
                     bool failed = alive && !conv;
                     if (wv::ballot(failed)) {
+                        unsigned long long nf = wv::ballot(lig < NN && !(z * 0.0 == 0.0));
+                        bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
                         bool warn = failed && zfinite;
                         bool die = failed && !zfinite;
                         if (lig == 0 && warn) {
@@ -1007,9 +1007,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                         if (lig == 0 && die && rbuf[RW_FIRST_NONFINITE] < 0) rbuf[RW_FIRST_NONFINITE] = n;
                         dead = dead || die;
                     }
-                    if (lig == 0 && alive) {
-                        rbuf[RW_ITERS_TOTAL] += its_sample;
-                        if (its_sample > rbuf[RW_ITERS_MAX]) rbuf[RW_ITERS_MAX] = its_sample;
+                    if (lig == 0 && alive) {   // fire-and-forget LDS atomics: no round trip to wait for
+                        wv::lds_add(&rbuf[RW_ITERS_TOTAL], (long long)its_sample);
+                        wv::lds_max(&rbuf[RW_ITERS_MAX], (long long)its_sample);
                     }
                 }
                 if (S::NSUB > 1) leave_sub(sc);

@@ -121,6 +121,14 @@ ACME_DEV double recip(double d) {
     return fma(x, e, x);
 }
 ACME_DEV int ffs32(int v) { return __ffs(v); }
+// LDS read-modify-write without a returned value (ds_add_u64 / ds_max_i64): nothing to wait for
+ACME_DEV void lds_add(long long *p, long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+ACME_DEV void lds_max(long long *p, long long v) {
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // scheduling fence: nothing is moved across (used to keep a batch of DPP broadcasts ahead of
 // the FMAs that consume them: a dependent dpp->fma pair costs ~17 cycles, batched ~9)
 ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -218,5 +218,7 @@ ACME_DEV int opaque(int v) { return v; }
 ACME_DEV unsigned long long pin(unsigned long long m) { return m; }
 ACME_DEV double sconst(double v) { return v; }
 ACME_DEV void sched_fence() {}
+ACME_DEV void lds_add(long long *p, long long v) { *p += v; }
+ACME_DEV void lds_max(long long *p, long long v) { if (v > *p) *p = v; }
 ACME_DEV bool lanes(unsigned long long mask) { return (mask >> (tid() & 63)) & 1ull; }
 }  // namespace wv
