@@ -961,7 +961,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     ACME_DBG("hom step lane %d need %d mode %d ha %.17g hbest %.17g conv %d its %d", lane, (int)need, mode, ha, hbest, (int)c, its);
                     its_sample += need ? its : 0;
                     conv = need ? c : conv;
-                    if (A.solver == SOLVER_SIMPLE) {
+                    // the usual case -- every instance that needed a solve got it from the direct
+                    // attempt -- skips the bisection bookkeeping
+                    if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c))) {
                         need = false;
                     } else {
                         bool direct = need && mode == 0;
