@@ -85,6 +85,15 @@ static inline int copy_h2d_async(void *d, const void *s, size_t n, stream_t st) 
 static inline int copy_d2h_async(void *d, const void *s, size_t n, stream_t st) {
     return (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st);
 }
+// strided host <-> device copies on a stream (a time slice of every instance's u / y rows)
+static inline int copy2d_h2d_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, stream_t st) {
+    return (int)hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, st);
+}
+static inline int copy2d_d2h_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, stream_t st) {
+    return (int)hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToHost, st);
+}
+static inline int stream_create_nonblocking(stream_t *st) { return (int)hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
+static inline int stream_destroy(stream_t st) { return st ? (int)hipStreamDestroy(st) : 0; }
 static inline int device_sync() { return (int)hipDeviceSynchronize(); }
 static inline int stream_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
 static inline int event_create(event_t *e) { return (int)hipEventCreate(e); }

@@ -130,7 +130,9 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
                             const acme_model *const *models);
 
 /* run!(runner, y, u): advance every instance by T samples (src/ACME.jl:650-664).
- * mem = ACME_MEM_HOST: u/y are host buffers (staged through HBM by the library);
+ * mem = ACME_MEM_HOST: u/y are host buffers, staged through HBM by the library (runs of 4096+
+ *   samples in time slices whose copies overlap the kernel on a second stream); the call returns
+ *   when y is complete;
  * mem = ACME_MEM_DEVICE: u/y are device pointers on the batch's device and `stream` is the
  * hipStream_t to launch on (NULL = default stream); the call is then asynchronous. */
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,

@@ -177,6 +177,15 @@ static inline int copy_h2d(void *d, const void *s, size_t n) { memcpy(d, s, n); 
 static inline int copy_d2h(void *d, const void *s, size_t n) { memcpy(d, s, n); return 0; }
 static inline int copy_h2d_async(void *d, const void *s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
 static inline int copy_d2h_async(void *d, const void *s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+static inline int copy2d_h2d_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, stream_t) {
+    for (size_t r = 0; r < height; ++r) memcpy((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return 0;
+}
+static inline int copy2d_d2h_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, stream_t st) {
+    return copy2d_h2d_async(d, dpitch, s, spitch, width, height, st);
+}
+static inline int stream_create_nonblocking(stream_t *st) { *st = nullptr; return 0; }
+static inline int stream_destroy(stream_t) { return 0; }
 static inline int device_sync() { return 0; }
 static inline int stream_sync(stream_t) { return 0; }
 static inline int event_create(event_t *e) { *e = new Ev(); return 0; }
