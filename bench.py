@@ -220,11 +220,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # ACME_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank code path on a single-GPU box (every rank
+    # on cuda:0, gloo instead of RCCL); never set by the driver
+    rehearsal = os.environ.get("ACME_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from acme_jl_amd.dist import broadcast_model
     from acme_jl_amd.model import DiscreteModel
