@@ -22,3 +22,15 @@ for solver,lim in ((HomotopySolver,None),(CachingHomotopySolver,8)):
     yref,its=oracle_run(m,u,cache_limit=lim)
     err=np.abs(y-yref).max(axis=(1,2))
     print(solver, "max err", err.max(), "n_warn", ra["n_warn"].sum(), "iters gpu/oracle", ra["iters_total"].sum(), its.sum(), "worst instance rel iters diff", np.abs(ra["iters_total"]-its).max()/its.max())
+
+# the other BASELINE circuits, one second each, both solver stacks
+from helpers import sweep_inputs
+for name, N, T in (("diodeclipper", 64, 44100), ("birdie_var_176k", 32, 176400), ("superover_fixed", 32, 44100)):
+    for solver, lim in ((HomotopySolver, None), (CachingHomotopySolver, 8)):
+        m = load(name, solver)
+        u = sweep_inputs(name, N, T)
+        r = ModelRunner(m, N)
+        y = r.run(u)
+        ra = r.report_arrays()
+        yref, its = oracle_run(m, u, cache_limit=lim)
+        print(name, solver, "max err", np.abs(y - yref).max(), "n_warn", ra["n_warn"].sum(), "iters gpu/oracle", ra["iters_total"].sum(), its.sum())
