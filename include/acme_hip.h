@@ -106,10 +106,13 @@ int acme_model_add_subproblem(acme_model *m, int nn, int nq, int np, const doubl
                               int n_elems, const int *elem_kind, const int *elem_qoff,
                               const int *elem_roff, const double *elem_par);
 /* optional performance hint: order[pos] = residual row (0-based, in element-table order)
- * handled by lane `pos`.  Listing the equations in their usual pivot order lets the
- * partially pivoted LU (src/solvers.jl:58-78) find its pivot in place, skipping the
- * cross-lane row interchange.  Pivot choice and arithmetic are those of the natural order
- * (only exact |pivot| ties could resolve differently).  n = 0 restores the natural order. */
+ * handled by lane `pos` when a batch is created.  The elimination keeps the row sitting in pivot
+ * position while every multiplier satisfies |l| <= 4 (threshold partial pivoting; the
+ * reference's setlhs!, src/solvers.jl:58-78, is the threshold 1) and only otherwise re-learns
+ * the order with the reference's first-strict-maximum search; listing the equations in their
+ * usual pivot order spares the first such searches.  Either way the factorisation is a valid LU
+ * of the same Jacobian: results of different row orders agree to rounding.  n = 0 restores the
+ * natural order. */
 int acme_model_set_row_order(acme_model *m, int sub, const int *order, int n);
 void acme_model_destroy(acme_model *m);
 /* dims = {nn, nq, np, nx, nu, ny} of the instantiated kernel shape the model runs in */
