@@ -41,8 +41,10 @@ enum RowFlags { RF_EARLY = 1, RF_KNEE = 2, RF_ILE = 4, RF_ILC = 8, RF_ETAEL = 16
 
 enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1, SOLVER_CACHING_HOMOTOPY = 2 };
 // CachingSolver on the GPU: per instance and sub-problem the last CACHE stored solutions (p, z),
-// first in first out, in LDS (the reference keeps every stored solution in a k-d tree)
-constexpr int CACHE = 8;
+// first in first out (the reference keeps every stored solution in a k-d tree).  The p's -- what
+// every lookup scans, one entry per lane -- live in LDS during a launch; the z's, read only on a
+// hit, stay in HBM.  HBM layout per sub-problem: cp[np][CACHE] | count, head | cz[nn][CACHE].
+constexpr int CACHE = 16;
 
 struct Dims {
     int nn, nq, np, nx, nu, ny;

@@ -62,9 +62,12 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
     static constexpr int ORIGIN1 = NP * OSTRIDE;              // one sub-problem: J^-1 * Jp
     static constexpr int ORIGIN = NSUBr * ORIGIN1 + GROUP;
-    // solution cache of one sub-problem of one instance: cp[NP][CACHE] | cz[NN][CACHE] | count, head
-    static constexpr int CACHE1 = (NP + NN) * CACHE + 2;
-    static constexpr int CACHEI = NSUBr * CACHE1;             // per instance
+    // solution cache of one sub-problem of one instance.  In LDS: cp[NP][CACHE] | count, head;
+    // in HBM the same followed by cz[NN][CACHE] (see acme_common.h)
+    static constexpr int CACHE1 = NP * CACHE + 2;             // LDS doubles per sub-problem
+    static constexpr int CACHEI = NSUBr * CACHE1;             // LDS doubles per instance
+    static constexpr int CACHE1H = (NP + NN) * CACHE + 2;     // HBM doubles per sub-problem
+    static constexpr int CACHEIH = NSUBr * CACHE1H;           // HBM doubles per instance
     // the solution caches sit at the end of the block's LDS and are only allocated (and touched) when
     // the batch runs the caching solver
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
@@ -465,7 +468,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double *const cache0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + WAVES_PER_BLOCK * S::ORIGIN + gib * S::CACHEI;
     // context of the sub-problem being solved (switched by enter_sub)
     double *ojp = ojp0;            // origin's J^-1 * Jp, row lig: [j * OS]
-    double *cch = cache0;          // solution cache of the current sub-problem
+    double *cch = cache0;          // solution cache of the current sub-problem: stored p's (LDS)
+    double *czg = A.cache + (valid ? inst : 0) * S::CACHEIH + S::CACHE1;   // ... and stored z's (HBM)
     const double *rowc_s = lds_rowc;
     const int *rowi_s = lds_rowi;
     {   // cooperative load of the model image(s) and the row tables
@@ -495,7 +499,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     for (int i = lig; i < S::SCRATCH; i += GROUP) ubuf[i] = 0.0;
     // the solution caches live in HBM between launches
     if (A.solver == SOLVER_CACHING_HOMOTOPY && valid)
-        for (int i = lig; i < S::CACHEI; i += GROUP) cache0[i] = A.cache[inst * S::CACHEI + i];
+        for (int s = 0; s < S::NSUBr; ++s)
+            for (int i = lig; i < S::CACHE1; i += GROUP)
+                cache0[s * S::CACHE1 + i] = A.cache[inst * S::CACHEIH + s * S::CACHE1H + i];
     wv::wave_fence();
 
     // Which residual row (equation) this lane evaluates.  It starts as the host's row-order
@@ -749,6 +755,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         rowi_s = lds_rowi + s * ROWI * GROUP;
         ojp = ojp0 + s * S::ORIGIN1;
         cch = cache0 + s * S::CACHE1;
+        czg = A.cache + (valid ? inst : 0) * S::CACHEIH + s * S::CACHE1H + S::CACHE1;
         lp = lps[s];
         lz = lzs[s];
         rowid = rowids[s];
@@ -812,12 +819,14 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // current extrapolation origin, it becomes the origin -- set_extrapolation_origin(base, p_c,
     // z_c) re-linearises there (:183-189) -- and a converged base solve that needed more than 5
     // iterations is stored, overwriting the oldest entry once the store is full (the reference
-    // keeps all of them in a k-d tree; on the bench grid 8 entries give 3.56 Newton iterations per
-    // sample against 3.48 unbounded and 6.36 without a cache).  Lane e < CACHE owns entry e.
+    // keeps all of them in a k-d tree).  Lane e owns entry e.  Capacity matters for the cells of the
+    // bench grid that are hard in steady state: their oracle costs 9.4 Newton iterations per sample
+    // without a cache, 4.5 with 8 entries, 3.02 with 16, 3.00 with 32 and 3.02 unbounded -- and a
+    // launch lasts as long as its slowest wave.
     const bool caching = A.solver == SOLVER_CACHING_HOMOTOPY;
     auto cached_solve = [&](double target, bool need, bool first, int &its) ACME_LAMBDA -> bool {
-        double *cp = cch, *cz = cch + NP * CACHE;
-        int *meta = reinterpret_cast<int *>(cch + (NP + NN) * CACHE);   // count, head
+        double *cp = cch, *cz = czg;
+        int *meta = reinterpret_cast<int *>(cch + NP * CACHE);   // count, head
         bool reorig = first;        // (lp, lz) not linearised yet: launch start, or new origin below
         if (caching) {
             const int count = meta[0];
@@ -836,7 +845,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             const bool hit = need && count > 0 && m < best;
             if (wv::ballot(hit)) {
                 const int e = hit ? idx : 0;
-                const double cpl = cp[(lig < NP ? lig : 0) * CACHE + e], czl = cz[(lig < NN ? lig : 0) * CACHE + e];
+                const double cpl = cp[(lig < NP ? lig : 0) * CACHE + e];
+                const double czl = (valid && caching) ? cz[(lig < NN ? lig : 0) * CACHE + e] : 0.0;   // HBM
                 lp = hit ? cpl : lp;
                 lz = hit ? czl : lz;
             }
@@ -857,7 +867,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 if (keep) {
                     const int slot = count < CACHE ? count : head;
                     if (lig < NP) cp[lig * CACHE + slot] = target;
-                    if (lig < NN) cz[lig * CACHE + slot] = z;
+                    if (valid && lig < NN) cz[lig * CACHE + slot] = z;   // HBM
                     if (lig == 0) {
                         meta[0] = count < CACHE ? count + 1 : count;
                         meta[1] = count < CACHE ? head : (head + 1) & (CACHE - 1);
@@ -1143,7 +1153,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             A.roworder[(inst * NSUB + s) * GROUP + lig] = rowids[s];
         });
         if (A.solver == SOLVER_CACHING_HOMOTOPY)
-            for (int i = lig; i < S::CACHEI; i += GROUP) A.cache[inst * S::CACHEI + i] = cache0[i];
+            for (int s = 0; s < S::NSUBr; ++s)
+                for (int i = lig; i < S::CACHE1; i += GROUP)
+                    A.cache[inst * S::CACHEIH + s * S::CACHE1H + i] = cache0[s * S::CACHE1 + i];
         if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
     }
 }

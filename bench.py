@@ -135,7 +135,7 @@ def _cpu_worker(args):
     for u in rows:
         r = RefRunner(m)
         if solver == CachingHomotopySolver:
-            r.set_cache_limit(8)      # the GPU's bounded store: same algorithm on both sides
+            r.set_cache_limit(16)      # the GPU's bounded store: same algorithm on both sides
         r.run(u)
         iters += r.report.iters_total
     return time.perf_counter() - t0, iters
@@ -327,7 +327,7 @@ def main():
                 f"examples/diodeclipper.jl, {n_per_gpu}-instance amplitude sweep 10mV..10V per GPU",
                 "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": FS,
                 "solver": model.solver,
-                "solver_note": "caching = the reference's default stack; GPU and CPU oracle keep the last 8 stored "
+                "solver_note": "caching = the reference's default stack; GPU and CPU oracle keep the last 16 stored "
                                "solutions per instance (reference: unbounded k-d tree), same lookup/store rules; "
                                "--solver homotopy runs HomotopySolver{SimpleSolver}",
                 "parallelism": f"instance-sharded x{world}",

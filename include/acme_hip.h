@@ -57,7 +57,7 @@ extern "C" {
 #define ACME_SOLVER_SIMPLE 0   /* SimpleSolver                  src/solvers.jl:151-236 */
 #define ACME_SOLVER_HOMOTOPY 1 /* HomotopySolver{SimpleSolver}  src/solvers.jl:247-302 */
 /* HomotopySolver{CachingSolver{SimpleSolver}} (src/solvers.jl:303-405, the reference's default
- * stack) with a BOUNDED store: per instance and sub-problem the last 8 stored solutions, first in
+ * stack) with a BOUNDED store: per instance and sub-problem the last 16 stored solutions, first in
  * first out, instead of the reference's ever-growing k-d tree.  Same lookup rule (a stored p
  * strictly nearer than the current extrapolation origin becomes the origin) and storing rule
  * (converged base solve that needed more than 5 iterations). */

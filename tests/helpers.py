@@ -62,7 +62,7 @@ def sweep_inputs(name, N, T, seed=0):
 
 def oracle_run(model, u, solver=None, cache_limit=None):
     """y [N, ny, T] from the CPU oracle, one fresh runner per instance.  ``cache_limit``: bounded
-    FIFO store for the CachingSolver stack (8 = what the GPU implements; None = the reference's
+    FIFO store for the CachingSolver stack (16 = what the GPU implements; None = the reference's
     unbounded store)."""
     from oracle.refpy import RefRunner
     ys, its = [], []

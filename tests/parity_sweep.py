@@ -15,7 +15,7 @@ from acme_jl_amd.runner import ModelRunner
 rng=np.random.default_rng(123)
 N,T=48,44100
 s=np.sin(2*np.pi*1000/44100*np.arange(T))
-for solver,lim in ((HomotopySolver,None),(CachingHomotopySolver,8)):
+for solver,lim in ((HomotopySolver,None),(CachingHomotopySolver,16)):
     m=load("superover_var", solver)
     u=np.zeros((N,4,T)); u[:,0]=rng.uniform(0.05,1.5,N)[:,None]*s; u[:,1]=rng.uniform(0,0.99,N)[:,None]; u[:,2]=rng.uniform(0,1,N)[:,None]; u[:,3]=rng.uniform(0,1,N)[:,None]
     r=ModelRunner(m,N); t0=time.time(); y=r.run(u); ra=r.report_arrays()
@@ -26,7 +26,7 @@ for solver,lim in ((HomotopySolver,None),(CachingHomotopySolver,8)):
 # the other BASELINE circuits, one second each, both solver stacks
 from helpers import sweep_inputs
 for name, N, T in (("diodeclipper", 64, 44100), ("birdie_var_176k", 32, 176400), ("superover_fixed", 32, 44100)):
-    for solver, lim in ((HomotopySolver, None), (CachingHomotopySolver, 8)):
+    for solver, lim in ((HomotopySolver, None), (CachingHomotopySolver, 16)):
         m = load(name, solver)
         u = sweep_inputs(name, N, T)
         r = ModelRunner(m, N)

@@ -305,7 +305,7 @@ def test_emulated_caching_solver(emu_lib):
         u = sweep_inputs(name, N, T)
         r = ModelRunner(m, N, lib=emu_lib)
         y = r.run(u)
-        yref, its = oracle_run(m, u, cache_limit=8)
+        yref, its = oracle_run(m, u, cache_limit=16)
         assert_close(y, yref)
         # same algorithm, same Newton paths: the counts agree unless a rounding-level flip of a
         # convergence test or of a nearest-entry decision sends one side down another path
@@ -328,7 +328,7 @@ def test_emulated_caching_decomposed_and_per_instance(emu_lib):
     assert len(m.subs) == 3
     u = sweep_inputs("superover_fixed", 3, 300)
     r = ModelRunner(m, 3, lib=emu_lib)
-    yref, its = oracle_run(m, u, cache_limit=8)
+    yref, its = oracle_run(m, u, cache_limit=16)
     assert_close(r.run(u), yref)
     assert np.abs(r.report_arrays()["iters_total"] - its).max() <= max(3, 0.1 * its.max())
     rng = np.random.Generator(np.random.PCG64(7))
@@ -338,7 +338,7 @@ def test_emulated_caching_decomposed_and_per_instance(emu_lib):
     u = np.tile(0.7 * sine(250)[None, None, :], (3, 1, 1))
     y = ModelRunner(models[0], 3, models=models, lib=emu_lib).run(u)
     for k in range(3):
-        yref, _ = oracle_run(models[k], u[k:k + 1], cache_limit=8)
+        yref, _ = oracle_run(models[k], u[k:k + 1], cache_limit=16)
         assert_close(y[k:k + 1], yref)
 
 

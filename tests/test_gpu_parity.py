@@ -364,7 +364,7 @@ def test_caching_solver(hip_lib):
         u = sweep_inputs(name, N, T)
         r = runner(hip_lib, m, N)
         y = r.run(u)
-        yref, its = oracle_run(m, u, cache_limit=8)
+        yref, its = oracle_run(m, u, cache_limit=16)
         assert_close(y, yref)
         ra = r.report_arrays()
         # same algorithm, same Newton paths: the counts agree unless a rounding-level flip of a
