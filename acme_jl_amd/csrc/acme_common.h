@@ -43,7 +43,8 @@ enum SolverKind { SOLVER_SIMPLE = 0, SOLVER_HOMOTOPY = 1, SOLVER_CACHING_HOMOTOP
 // CachingSolver on the GPU: per instance and sub-problem the last CACHE stored solutions (p, z),
 // first in first out (the reference keeps every stored solution in a k-d tree).  The p's -- what
 // every lookup scans, one entry per lane -- live in LDS during a launch; the z's, read only on a
-// hit, stay in HBM.  HBM layout per sub-problem: cp[np][CACHE] | count, head | cz[nn][CACHE].
+// hit, stay in HBM.  HBM layout per sub-problem: cp[np][CACHE] | count, head | cz[CACHE][nn] (entry-major: the nn lanes of
+// an instance read / write one contiguous line).
 constexpr int CACHE = 16;
 
 struct Dims {

@@ -846,7 +846,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             if (wv::ballot(hit)) {
                 const int e = hit ? idx : 0;
                 const double cpl = cp[(lig < NP ? lig : 0) * CACHE + e];
-                const double czl = (valid && caching) ? cz[(lig < NN ? lig : 0) * CACHE + e] : 0.0;   // HBM
+                const double czl = (valid && caching) ? cz[e * NN + (lig < NN ? lig : 0)] : 0.0;   // HBM, one line
                 lp = hit ? cpl : lp;
                 lz = hit ? czl : lz;
             }
@@ -867,7 +867,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 if (keep) {
                     const int slot = count < CACHE ? count : head;
                     if (lig < NP) cp[lig * CACHE + slot] = target;
-                    if (valid && lig < NN) cz[lig * CACHE + slot] = z;   // HBM
+                    if (valid && lig < NN) cz[slot * NN + lig] = z;   // HBM, entry-major: one coalesced line
                     if (lig == 0) {
                         meta[0] = count < CACHE ? count + 1 : count;
                         meta[1] = count < CACHE ? head : (head + 1) & (CACHE - 1);
