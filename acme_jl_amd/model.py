@@ -61,7 +61,7 @@ class DiscreteModel:
     ``solver`` defaults to ``HomotopySolver{SimpleSolver}``.  The reference's default additionally
     wraps a ``CachingSolver`` (a per-stream, unboundedly growing k-d tree of stored solutions that
     only changes Newton's start point): ``solver=CachingHomotopySolver`` selects the GPU's
-    bounded variant of it (the last 8 stored solutions per instance, same lookup and storing
+    bounded variant of it (the last 16 stored solutions per instance, same lookup and storing
     rules; converged results agree within the solver tolerance, iteration counts follow the
     oracle's bounded variant).
     """

@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--samples", type=int, default=FS, help="samples per step")
     ap.add_argument("--solver", default="caching", choices=["caching", "homotopy", "simple"],
                     help="caching = HomotopySolver{CachingSolver{SimpleSolver}}, the reference's default stack "
-                         "(GPU: bounded 8-entry store per instance); homotopy = HomotopySolver{SimpleSolver}")
+                         "(GPU: bounded 16-entry store per instance); homotopy = HomotopySolver{SimpleSolver}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=None)
     args = ap.parse_args()
