@@ -57,6 +57,13 @@ def grid_inputs(workload, rank, world, n_per_gpu, T):
         return "diodeclipper", None, amp
     if workload == "superover_montecarlo":   # BASELINE config 4: models derived in montecarlo_models()
         return "superover_fixed", None, 1.0
+    if workload == "birdie_grid":            # BASELINE config 5: amplitude x vol grid, vol fastest
+        if total % 128:
+            raise SystemExit("birdie_grid needs a multiple of 128 instances (128 vol values per amplitude)")
+        na = total // 128
+        amp = 10.0 ** (-2 + 2.5 * (idx // 128) / max(na - 1, 1))
+        vol = 0.01 + 0.99 * (idx % 128) / 127.0
+        return "birdie_var_176k", vol[:, None], amp
     raise ValueError(workload)
 
 
@@ -75,9 +82,9 @@ def montecarlo_models(rank, n_per_gpu):
     return derive_batch(make, Fraction(1, 44100), vals)
 
 
-def make_u(torch, dev, model, pots, amp, n, T):
+def make_u(torch, dev, model, pots, amp, n, T, fs=FS):
     t = torch.arange(T, dtype=torch.float64, device=dev)
-    sig = torch.sin(2 * np.pi * 1000.0 / FS * t)
+    sig = torch.sin(2 * np.pi * 1000.0 / fs * t)
     u = torch.empty((n, T, model.nu), dtype=torch.float64, device=dev)
     if np.isscalar(amp):
         u[:, :, 0] = amp * sig[None, :]
@@ -154,7 +161,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24):
+def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     """Time the CPU oracle on a bounded, evenly spread sample of the same workload: one
     worker process per host core, `per_core` instance streams of T_cpu samples each (the
     reference's DiscreteModel is single-threaded and non-re-entrant, so independent per-core
@@ -166,7 +173,7 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24):
     cores = host_cores()
     n = len(pots) if pots is not None else len(amp)
     pick = np.linspace(0, n - 1, cores * per_core).astype(int)
-    sig = np.sin(2 * np.pi * 1000.0 / FS * np.arange(T_cpu))
+    sig = np.sin(2 * np.pi * 1000.0 / fs * np.arange(T_cpu))
     jobs = []
     for w in range(cores):
         rows = []
@@ -197,12 +204,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="superover_grid",
-                    choices=["superover_grid", "diodeclipper_sweep", "superover_montecarlo"],
+                    choices=["superover_grid", "diodeclipper_sweep", "superover_montecarlo", "birdie_grid"],
                     help="superover_grid = BASELINE config 3 (the headline, default); diodeclipper_sweep = "
-                         "config 2; superover_montecarlo = config 4 (per-instance model blocks)")
+                         "config 2; superover_montecarlo = config 4 (per-instance model blocks); birdie_grid = "
+                         "config 5 (176.4 kHz, 2048 instances per GPU, HomotopySolver unless --solver is given)")
     ap.add_argument("--instances", type=int, default=None, help="instances per GPU")
-    ap.add_argument("--samples", type=int, default=FS, help="samples per step")
-    ap.add_argument("--solver", default="caching", choices=["caching", "homotopy", "simple"],
+    ap.add_argument("--samples", type=int, default=None, help="samples per step (default: 1 s of signal)")
+    ap.add_argument("--solver", default=None, choices=["caching", "homotopy", "simple"],
                     help="caching = HomotopySolver{CachingSolver{SimpleSolver}}, the reference's default stack "
                          "(GPU: bounded 16-entry store per instance); homotopy = HomotopySolver{SimpleSolver}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -238,8 +246,10 @@ def main():
     from acme_jl_amd.model import DiscreteModel
     from acme_jl_amd.runner import ModelRunner
 
-    n_per_gpu = args.instances or (4096 if args.workload == "diodeclipper_sweep" else 8192)
-    T = args.samples
+    n_per_gpu = args.instances or {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(args.workload, 8192)
+    fs = 176400 if args.workload == "birdie_grid" else FS
+    T = args.samples or fs
+    args.solver = args.solver or ("homotopy" if args.workload == "birdie_grid" else "caching")
     fixture, pots, amp = grid_inputs(args.workload, rank, world, n_per_gpu, T)
     # rank 0 owns the model block; everyone else receives it over RCCL (xGMI)
     from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver, SimpleSolver
@@ -260,7 +270,7 @@ def main():
         setup["upload_s"] = time.perf_counter() - t0
     else:
         runner = ModelRunner(model, n_per_gpu, device=local_rank)
-    u = make_u(torch, dev, model, pots, amp, n_per_gpu, T)
+    u = make_u(torch, dev, model, pots, amp, n_per_gpu, T, fs)
     y = torch.empty((n_per_gpu, T, model.ny), dtype=torch.float64, device=dev)
 
     def sync():
@@ -308,8 +318,9 @@ def main():
         abytes = algorithmic_bytes(model, n_per_gpu, T)
         achieved = abytes / (last_ms * 1e-3) / 1e9
         out = {
-            "metric": "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)"
-            if args.workload == "diodeclipper_sweep" else "circuit-instance*samples/sec (superover, 44.1 kHz)",
+            "metric": {"diodeclipper_sweep": "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)",
+                       "birdie_grid": "circuit-instance*samples/sec (birdie, 176.4 kHz)"}.get(
+                           args.workload, "circuit-instance*samples/sec (superover, 44.1 kHz)"),
             "value": value, "unit": "circuit-instance*samples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -324,8 +335,12 @@ def main():
                  "instances per GPU: R, C, pot tracks * (1 + 0.05 U(-1,1)), PCG64 seed 20250905, one model "
                  "block per instance; 1 kHz unit sine")
                 if args.workload == "superover_montecarlo" else
+                (f"examples/birdie.jl at 176.4 kHz, vol as input (nn=4,nq=9,np=3,nx=3,nu=2), {n_per_gpu} instances "
+                 f"per GPU: {n_per_gpu * world // 128} amplitudes 10^(-2..0.5) x 128 vol in linspace(0.01,1), "
+                 "1 kHz sine")
+                if args.workload == "birdie_grid" else
                 f"examples/diodeclipper.jl, {n_per_gpu}-instance amplitude sweep 10mV..10V per GPU",
-                "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": FS,
+                "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": fs,
                 "solver": model.solver,
                 "solver_note": "caching = the reference's default stack; GPU and CPU oracle keep the last 16 stored "
                                "solutions per instance (reference: unbounded k-d tree), same lookup/store rules; "
@@ -350,8 +365,8 @@ def main():
         if out["roofline"]["fp64_tflops"] is not None:
             out["roofline"]["fp64_frac"] = out["roofline"]["fp64_tflops"] / FP64_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
-            T_cpu = args.cpu_samples or T
-            out["cpu_baseline"] = cpu_baseline(fixture, model, pots, amp, T_cpu)
+            T_cpu = args.cpu_samples or min(T, FS)
+            out["cpu_baseline"] = cpu_baseline(fixture, model, pots, amp, T_cpu, fs=fs)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -385,3 +385,24 @@ def test_caching_solver(hip_lib):
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(5)).cuda()
     y3 = runner(hip_lib, m, N).run_torch(u[perm].contiguous())
     assert torch.equal(y1[perm], y3)
+
+
+def test_full_size_birdie_grid(hip_lib):
+    """BASELINE config 5's per-GPU share (2048 birdie instances at 176.4 kHz, amplitude x vol grid,
+    HomotopySolver): block-split invariance at full width and spot parity with the oracle."""
+    import torch
+    import bench
+    m = load("birdie_var_176k")
+    N, T = 2048, 3000
+    _, vol, amp = bench.grid_inputs("birdie_grid", 0, 1, N, T)
+    u = bench.make_u(torch, torch.device("cuda"), m, vol, amp, N, T, fs=176400)
+    r1 = runner(hip_lib, m, N)
+    y1 = r1.run_torch(u)
+    r1.check()
+    r2 = runner(hip_lib, m, N)
+    y2 = torch.cat([r2.run_torch(u[:, a:b].contiguous()) for a, b in ((0, 1), (1, 2000), (2000, T))], dim=1)
+    assert torch.equal(y1, y2)
+    idx = np.array([0, 127, 128, 1000, 2047])
+    yref, _ = oracle_run(m, u[idx].cpu().numpy().transpose(0, 2, 1))
+    assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
+    assert (r1.report_arrays()["n_warn"] == 0).all()
