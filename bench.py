@@ -235,8 +235,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ACME_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, broadcast, all-reduce,
+    # barriers) even at world size 1 -- what the single-GPU box can check of it (tests)
+    use_dist = world > 1 or os.environ.get("ACME_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -256,7 +260,7 @@ def main():
     solver = {"caching": CachingHomotopySolver, "homotopy": HomotopySolver, "simple": SimpleSolver}[args.solver]
     model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver) \
         if rank == 0 else None
-    model = broadcast_model(model, src=0, device=dev) if world > 1 else model
+    model = broadcast_model(model, src=0, device=dev) if use_dist else model
 
     setup = {}
     if args.workload == "superover_montecarlo":
@@ -274,7 +278,7 @@ def main():
     y = torch.empty((n_per_gpu, T, model.ny), dtype=torch.float64, device=dev)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -297,7 +301,7 @@ def main():
     stats = torch.tensor([elapsed, float(ra["iters_total"].sum()), float(ra["n_warn"].sum()),
                           float((ra["first_nonfinite"] >= 0).sum()), float(ra["iters_max"].max()),
                           last_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -368,7 +372,7 @@ def main():
             T_cpu = args.cpu_samples or min(T, FS)
             out["cpu_baseline"] = cpu_baseline(fixture, model, pots, amp, T_cpu, fs=fs)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
 seeded inputs, plus the reference's doctest golden vectors.  Run on the MI355X box with
 `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -406,3 +408,24 @@ def test_full_size_birdie_grid(hip_lib):
     yref, _ = oracle_run(m, u[idx].cpu().numpy().transpose(0, 2, 1))
     assert_close(y1[idx].cpu().numpy().transpose(0, 2, 1), yref)
     assert (r1.report_arrays()["n_warn"] == 0).all()
+
+
+def test_bench_multirank_path_over_rccl(hip_lib):
+    """The driver's multi-GPU command line (torch.distributed.run, one rank per GPU, backend
+    "nccl" = RCCL) with one rank, forced through the multi-rank code path: RCCL initialisation,
+    model broadcast, counter all-reduces and barriers all run on the real device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACME_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "1", "--warmup", "1", "--instances", "256", "--samples", "2000",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e6
+    assert rec["config"]["n_warn"] == 0 and rec["config"]["n_nonfinite_instances"] == 0
