@@ -53,8 +53,11 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     a = shlex.split(os.environ.get("BENCH_ARGS", ""))
     def opt(name, default):
         return a[a.index(name) + 1] if name in a else default
-    rec = {"runs": [{"workload": opt("--workload", "superover_grid"), "instances": int(opt("--instances", 8192)),
-                     "samples": int(opt("--samples", 44100)),
+    wl = opt("--workload", "superover_grid")
+    n_def = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(wl, 8192)      # bench.py's defaults
+    t_def = 176400 if wl == "birdie_grid" else 44100
+    rec = {"runs": [{"workload": wl, "instances": int(opt("--instances", n_def)),
+                     "samples": int(opt("--samples", t_def)),
                      "fetch_size_kb_per_launch": vals["FETCH_SIZE"], "write_size_kb_per_launch": vals["WRITE_SIZE"],
                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the launches of "
                                "python bench.py --no-cpu-baseline " + " ".join(a)}]}
