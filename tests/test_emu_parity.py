@@ -370,3 +370,17 @@ def test_emulated_sliced_host_run(emu_lib):
     assert np.array_equal(y_host, np.transpose(yb, (0, 2, 1)))
     yref, _ = oracle_run(m, u)
     assert_close(y_host, yref)
+
+
+def test_emulated_empty_and_single_sample_runs(emu_lib):
+    """Edge cases of run!: T = 0 (empty u -> empty y, state untouched), T = 1, and the 2-D
+    single-instance call; pieces concatenate to the one-call result bit for bit."""
+    m = load("superover_fixed")
+    u = sweep_inputs("superover_fixed", 3, 40)
+    r = emu_runner(emu_lib, m, 3)
+    assert r.run(u[:, :, :0]).shape == (3, 1, 0)
+    y = np.concatenate([r.run(u[:, :, :1]), r.run(u[:, :, 1:1]), r.run(u[:, :, 1:])], axis=2)
+    yf = emu_runner(emu_lib, m, 3).run(u)
+    assert np.array_equal(y, yf)
+    y1 = emu_runner(emu_lib, m, 1).run(u[0])
+    assert y1.shape == (1, 40) and np.array_equal(y1, yf[0])

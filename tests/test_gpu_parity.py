@@ -429,3 +429,19 @@ def test_bench_multirank_path_over_rccl(hip_lib):
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 1e6
     assert rec["config"]["n_warn"] == 0 and rec["config"]["n_nonfinite_instances"] == 0
+
+
+def test_empty_and_single_sample_runs(hip_lib):
+    """Edge cases of run!: T = 0 (empty u -> empty y, state untouched), T = 1, and the 2-D
+    single-instance call; pieces concatenate to the one-call result bit for bit."""
+    m = load("superover_fixed")
+    u = sweep_inputs("superover_fixed", 3, 40)
+    r = runner(hip_lib, m, 3)
+    assert r.run(u[:, :, :0]).shape == (3, 1, 0)
+    y = np.concatenate([r.run(u[:, :, :1]), r.run(u[:, :, 1:1]), r.run(u[:, :, 1:])], axis=2)
+    yf = runner(hip_lib, m, 3).run(u)
+    assert np.array_equal(y, yf)
+    y1 = runner(hip_lib, m, 1).run(u[0])
+    assert y1.shape == (1, 40) and np.array_equal(y1, yf[0])
+    yref, _ = oracle_run(m, u)
+    assert_close(yf, yref)

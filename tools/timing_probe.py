@@ -21,12 +21,13 @@ NAMES = ["post(y,x,io)", "pre(p)", "setup(set_p,extrap)", "evaluate", "pivot+ado
 
 def main(T=2205, n=8192):
     dev = torch.device("cuda:0")
-    fixture, pots, amp = bench.grid_inputs("superover_grid", 0, 1, n, T)
+    workload = os.environ.get("ACME_PROBE_WORKLOAD", "superover_grid")      # or birdie_grid, diodeclipper_sweep
+    fixture, pots, amp = bench.grid_inputs(workload, 0, 1, n, T)
     from acme_jl_amd.model import DiscreteModel
     from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
     solver = HomotopySolver if os.environ.get("ACME_PROBE_SOLVER") == "homotopy" else CachingHomotopySolver
     model = DiscreteModel.load(os.path.join(bench.ROOT, "tests", "golden", fixture + ".json"), solver=solver)
-    u = bench.make_u(torch, dev, model, pots, amp, n, T)
+    u = bench.make_u(torch, dev, model, pots, amp, n, T, 176400 if workload == "birdie_grid" else bench.FS)
     r = R.ModelRunner(model, n)
     y = r.run_torch(u)
     torch.cuda.synchronize()
