@@ -37,3 +37,18 @@ def test_product_package_never_imports_the_oracle():
                 assert "oracle" not in text.replace("oracle/acme_ref", "").lower() or f == "hostsolve.py" or \
                     "import oracle" not in text and "from oracle" not in text, f
                 assert "import oracle" not in text and "from oracle" not in text and "libacme_emu" not in text, f
+
+
+def test_plain_c_client_links_and_fails_loudly_without_gpu():
+    """examples/abi_demo.c (plain C over include/acme_hip.h) builds against the product library;
+    on a GPU-less box it must stop with the no-device error, not compute anything."""
+    import subprocess
+    import pytest
+    import __graft_entry__ as g
+    from acme_jl_amd import runner
+    exe = g.build_abi_demo()
+    if runner.Library(runner.DEFAULT_LIBRARY).device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1
+    assert "no HIP device" in out.stderr and "no CPU fallback" in out.stderr

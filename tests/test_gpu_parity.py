@@ -445,3 +445,17 @@ def test_empty_and_single_sample_runs(hip_lib):
     assert y1.shape == (1, 40) and np.array_equal(y1, yf[0])
     yref, _ = oracle_run(m, u)
     assert_close(yf, yref)
+
+
+def test_plain_c_client_reproduces_the_doctest(hip_lib):
+    """examples/abi_demo.c: the C ABI driven from plain C (host buffers, default solver stack)
+    reproduces the reference documentation's diode-clipper output (gettingstarted.md:106-113)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "abi_demo")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        exe = g.build_abi_demo()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "doctest vector reproduced" in out.stdout
