@@ -95,12 +95,9 @@ def make_u(torch, dev, model, pots, amp, n, T, fs=FS):
     return u
 
 
-def pmc_traffic(workload, n, T):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    written by tools/profile_gpu.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this
-    command), or None if no pass for this exact workload is on file.  Reads = 2 x FETCH_SIZE:
-    gfx950 tallies this kernel's coalesced reads at half their size (calibrated on the
-    known byte count of the u stream)."""
+def pmc_record(workload, n, T):
+    """The committed rocprofv3 PMC passes of this exact workload (profiles/pmc_traffic.json, written
+    by tools/profile_gpu.sh: separate --pmc runs of this command), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             rec = json.load(fh)
@@ -108,8 +105,27 @@ def pmc_traffic(workload, n, T):
         return None
     for r in rec.get("runs", []):
         if r.get("workload") == workload and r.get("instances") == n and r.get("samples") == T:
-            return 1024.0 * (2.0 * r["fetch_size_kb_per_launch"] + r["write_size_kb_per_launch"])
+            return r
     return None
+
+
+def pmc_traffic(workload, n, T):
+    """HBM bytes per launch from the PMC passes, or None if no pass for this exact workload is on
+    file.  Reads = 2 x FETCH_SIZE: gfx950 tallies this kernel's coalesced reads at half their size
+    (calibrated on the known byte count of the u stream)."""
+    r = pmc_record(workload, n, T)
+    if r is None:
+        return None
+    return 1024.0 * (2.0 * r["fetch_size_kb_per_launch"] + r["write_size_kb_per_launch"])
+
+
+def pmc_valu_issue_frac(workload, n, T, n_simd=1024, n_xcd=8):
+    """Share of the chip's VALU issue slots the profiled launch used: SQ_INSTS_VALU wave-instructions
+    against one 64-lane fp64 instruction per SIMD every 4 cycles (GRBM_GUI_ACTIVE sums the XCDs)."""
+    r = pmc_record(workload, n, T)
+    if r is None or "sq_insts_valu_per_launch" not in r:
+        return None
+    return r["sq_insts_valu_per_launch"] / (n_simd * r["grbm_gui_active_per_launch"] / n_xcd / 4.0)
 
 
 def algorithmic_bytes(model, n, T):
@@ -364,6 +380,9 @@ def main():
                 "fp64_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
                 / (last_ms * 1e-3) / 1e12 if model.subs else None,
                 "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+                "valu_issue_frac": pmc_valu_issue_frac(args.workload, n_per_gpu, T),
+                "valu_issue_note": "VALU wave-instructions issued / (1024 SIMDs x cycles / 4), from the committed "
+                                   "rocprofv3 PMC pass of this workload (profiles/pmc_traffic.json); null if none",
             },
         }
         if out["roofline"]["fp64_tflops"] is not None:

@@ -59,6 +59,8 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     rec = {"runs": [{"workload": wl, "instances": int(opt("--instances", n_def)),
                      "samples": int(opt("--samples", t_def)),
                      "fetch_size_kb_per_launch": vals["FETCH_SIZE"], "write_size_kb_per_launch": vals["WRITE_SIZE"],
+                     "sq_insts_valu_per_launch": vals.get("SQ_INSTS_VALU"),
+                     "grbm_gui_active_per_launch": vals.get("GRBM_GUI_ACTIVE"), "sq_waves": vals.get("SQ_WAVES"),
                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the launches of "
                                "python bench.py --no-cpu-baseline " + " ".join(a)}]}
     with open(out + "/pmc_traffic.json", "w") as fh:
