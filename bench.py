@@ -329,6 +329,12 @@ def main():
         iters_total, n_warn, n_dead, iters_max = (float(stats[1]), float(stats[2]), float(stats[3]),
                                                   float(stats[4]))
     checksum = float(torch.nan_to_num(y).abs().sum())
+    if os.environ.get("ACME_BENCH_FORCE_DIST") == "1":
+        # test-only (never set by the driver): the optional output collection of SURVEY 8(e) over the
+        # same backend, on a small slice, outside the timed region
+        from acme_jl_amd.dist import gather_outputs
+        part = gather_outputs(y[:4].contiguous(), [4] * world, dst=0)
+        assert rank != 0 or (tuple(part.shape) == (4 * world, T, model.ny) and torch.equal(part[:4], y[:4]))
 
     if rank == 0:
         units = world * n_per_gpu * T * args.steps
