@@ -249,14 +249,36 @@ class ModelRunner:
             raise DimensionMismatch(
                 f"input matrix has {ucols} columns, output matrix has {ycols} columns")
 
-    def run(self, u, y=None, check=True):
+    def run(self, u, y=None, check=True, time_major=False):
         """``run!(runner, u)`` / ``run!(runner, y, u)`` with numpy arrays.
 
         ``u``: (nu, T) for a single instance, else (N, nu, T); returns ``y`` of shape
         (ny, T) resp. (N, ny, T).  Raises like the reference when an instance hits a
-        non-finite result and warns on convergence failures (unless ``check=False``)."""
+        non-finite result and warns on convergence failures (unless ``check=False``).
+
+        ``time_major=True``: ``u`` is (N, T, nu) and ``y`` (N, T, ny) -- the memory layout of the
+        C ABI (and of Julia's nu x T matrices), passed through without the two transposing copies
+        the default shapes cost when nu or ny exceed 1."""
         m = self.model
         u = np.asarray(u, dtype=np.float64)
+        if time_major:
+            if u.ndim != 3 or u.shape[0] != self.n:
+                raise DimensionMismatch(f"input must have shape ({self.n}, T, {m.nu})")
+            T = u.shape[1]
+            if y is not None:
+                if not (isinstance(y, np.ndarray) and y.dtype == np.float64 and y.flags.c_contiguous):
+                    raise TypeError("y must be a C-contiguous float64 array")
+                if y.ndim != 3 or y.shape[0] != self.n:
+                    raise DimensionMismatch(f"output must have shape ({self.n}, T, {m.ny})")
+                self._check_io(u.shape[2], y.shape[2], T, y.shape[1])
+            else:
+                self._check_io(u.shape[2], m.ny, T, T)
+                y = np.empty((self.n, T, m.ny), dtype=np.float64)
+            ub = np.ascontiguousarray(u)
+            self.lib.check(self.lib.L.acme_batch_run(self.h, ub.ctypes.data, y.ctypes.data, T, ACME_MEM_HOST, None))
+            if check:
+                self.check()
+            return y
         single = u.ndim == 2
         if single:
             if self.n != 1:

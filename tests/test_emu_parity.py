@@ -384,3 +384,23 @@ def test_emulated_empty_and_single_sample_runs(emu_lib):
     assert np.array_equal(y, yf)
     y1 = emu_runner(emu_lib, m, 1).run(u[0])
     assert y1.shape == (1, 40) and np.array_equal(y1, yf[0])
+
+
+def test_emulated_time_major_run(emu_lib):
+    """run(..., time_major=True) takes (N, T, nu) / returns (N, T, ny) -- the C ABI's own layout --
+    and gives the bits of the default (N, nu, T) call; shape errors are DimensionMismatch."""
+    from acme_jl_amd.runner import DimensionMismatch
+    m = load("superover_var")
+    u = sweep_inputs("superover_var", 3, 60)
+    y = emu_runner(emu_lib, m, 3).run(u)
+    ut = np.ascontiguousarray(u.transpose(0, 2, 1))
+    r = emu_runner(emu_lib, m, 3)
+    yt = r.run(ut, time_major=True)
+    assert yt.shape == (3, 60, 1) and np.array_equal(yt.transpose(0, 2, 1), y)
+    out = np.empty((3, 60, 1))
+    r2 = emu_runner(emu_lib, m, 3)
+    assert r2.run(ut, out, time_major=True) is out and np.array_equal(out, yt)
+    with pytest.raises(DimensionMismatch):
+        r2.run(ut[:, :, :3], time_major=True)
+    with pytest.raises(DimensionMismatch):
+        r2.run(ut, np.empty((3, 59, 1)), time_major=True)
