@@ -109,56 +109,41 @@ ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 // library routine.  exp(+-inf) gives NaN here (the library gives inf / 0): both make the residual
 // non-finite only in states the solver has already lost.
 ACME_DEV double exp_junction(double x) {
-    using wv::sconst;
-    const double k = rint(x * sconst(1.4426950408889634));
-    double r = fma(-k, sconst(6.93147180369123816490e-01), x);
-    r = fma(-k, sconst(1.90821492927058770002e-10), r);
-    double p = fma(r, sconst(1.6059043836821613e-10), sconst(2.08767569878681e-09));   // 1/13!, 1/12!
-    p = fma(p, r, sconst(2.505210838544172e-08));     // 1/11!
-    p = fma(p, r, sconst(2.755731922398589e-07));     // 1/10!
-    p = fma(p, r, sconst(2.7557319223985893e-06));    // 1/9!
-    p = fma(p, r, sconst(2.48015873015873e-05));      // 1/8!
-    p = fma(p, r, sconst(1.984126984126984e-04));     // 1/7!
-    p = fma(p, r, sconst(1.388888888888889e-03));     // 1/6!
-    p = fma(p, r, sconst(8.333333333333333e-03));     // 1/5!
-    p = fma(p, r, sconst(4.1666666666666664e-02));    // 1/4!
-    p = fma(p, r, sconst(1.6666666666666666e-01));    // 1/3!
+    const wv::ExpTab t = wv::load_exp_tab();   // the 16 constants, two scalar loads
+    const double k = rint(x * t[0]);
+    double r = fma(-k, t[1], x);
+    r = fma(-k, t[2], r);
+    double p = fma(r, t[3], t[4]);                                                // 1/13!, 1/12!
+    // (sconst: keep each coefficient a scalar operand of v_fma_f64 -- the compiler otherwise copies it
+    // to vector registers to use the shorter v_fmac encoding, three instructions per step)
+    sfor<5, 14>([&](auto ic) ACME_LAMBDA { p = fma(p, r, wv::sconst(t[decltype(ic)::value])); });   // 1/11! .. 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double kc = fmin(fmax(k, -2100.0), 2100.0);
-    return ldexp(p, (int)kc);
+    return ldexp(p, (int)wv::clamp_s(k, t[14], t[15]));
 }
 // two exponentials at once: the same arithmetic as exp_junction on each argument, written out
-// in lockstep so that the two dependency chains interleave and every coefficient is
-// materialised once for both
+// in lockstep so that the two dependency chains interleave and the constants are loaded once
 ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb) {
-    using wv::sconst;
-    const double l2e = sconst(1.4426950408889634), ln2h = sconst(6.93147180369123816490e-01),
-                 ln2l = sconst(1.90821492927058770002e-10);
-    const double ka = rint(xa * l2e), kb = rint(xb * l2e);
-    double ra = fma(-ka, ln2h, xa), rb = fma(-kb, ln2h, xb);
-    ra = fma(-ka, ln2l, ra);
-    rb = fma(-kb, ln2l, rb);
-    double c = sconst(1.6059043836821613e-10), d = sconst(2.08767569878681e-09);
-    double pa = fma(ra, c, d), pb = fma(rb, c, d);
-#define ACME_EXP2_STEP(coef) do { const double c_ = (coef); pa = fma(pa, ra, c_); pb = fma(pb, rb, c_); } while (0)
-    ACME_EXP2_STEP(sconst(2.505210838544172e-08));
-    ACME_EXP2_STEP(sconst(2.755731922398589e-07));
-    ACME_EXP2_STEP(sconst(2.7557319223985893e-06));
-    ACME_EXP2_STEP(sconst(2.48015873015873e-05));
-    ACME_EXP2_STEP(sconst(1.984126984126984e-04));
-    ACME_EXP2_STEP(sconst(1.388888888888889e-03));
-    ACME_EXP2_STEP(sconst(8.333333333333333e-03));
-    ACME_EXP2_STEP(sconst(4.1666666666666664e-02));
-    ACME_EXP2_STEP(sconst(1.6666666666666666e-01));
-    ACME_EXP2_STEP(0.5);
-    ACME_EXP2_STEP(1.0);
-    ACME_EXP2_STEP(1.0);
-#undef ACME_EXP2_STEP
-    const double lo = sconst(-2100.0), hi = sconst(2100.0);
-    ea = ldexp(pa, (int)fmin(fmax(ka, lo), hi));
-    eb = ldexp(pb, (int)fmin(fmax(kb, lo), hi));
+    const wv::ExpTab t = wv::load_exp_tab();
+    const double ka = rint(xa * t[0]), kb = rint(xb * t[0]);
+    double ra = fma(-ka, t[1], xa), rb = fma(-kb, t[1], xb);
+    ra = fma(-ka, t[2], ra);
+    rb = fma(-kb, t[2], rb);
+    double pa = fma(ra, t[3], t[4]), pb = fma(rb, t[3], t[4]);
+    sfor<5, 14>([&](auto ic) ACME_LAMBDA {
+        constexpr int i = decltype(ic)::value;
+        pa = fma(pa, ra, t[i]);
+        pb = fma(pb, rb, t[i]);
+    });
+    pa = fma(pa, ra, 0.5);
+    pb = fma(pb, rb, 0.5);
+    pa = fma(pa, ra, 1.0);
+    pb = fma(pb, rb, 1.0);
+    pa = fma(pa, ra, 1.0);
+    pb = fma(pb, rb, 1.0);
+    ea = ldexp(pa, (int)wv::clamp_s(ka, t[14], t[15]));
+    eb = ldexp(pb, (int)wv::clamp_s(kb, t[14], t[15]));
 }
 ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 

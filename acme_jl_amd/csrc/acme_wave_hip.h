@@ -150,4 +150,34 @@ ACME_DEV unsigned long long pin(unsigned long long m) { asm volatile("" : "+s"(m
 // program order, which serialised the two interleaved exp() polynomial chains (-5 %).
 ACME_DEV double sconst(double v) { asm("" : "+s"(v)); return v; }
 
+// The 16 constants of the junction exponential as ONE table in constant memory, brought into scalar
+// registers by two s_load_dwordx16 per call instead of two s_mov_b32 per constant.
+//   0 log2(e)  1 ln2_hi  2 ln2_lo  3..13 1/13! .. 1/3!  14 -2100  15 2100
+__constant__ double acme_exp_tab[16] = {
+    1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07,
+    2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03,
+    8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, -2100.0, 2100.0};
+typedef double d8_t __attribute__((ext_vector_type(8)));
+struct ExpTab {
+    d8_t lo8, hi8;
+    ACME_DEV double operator[](int i) const { return i < 8 ? lo8[i] : hi8[i - 8]; }
+};
+// max(min(k, hi), lo) with scalar-register bounds; as instructions, so that the compiler does not
+// add a canonicalising v_max for bounds whose origin (a scalar load) it cannot see
+ACME_DEV double clamp_s(double k, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(k), "s"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "s"(hi));
+    return r;
+}
+ACME_DEV ExpTab load_exp_tab() {
+    ExpTab t;
+    const double *p = acme_exp_tab;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(t.lo8), "=s"(t.hi8)
+                 : "s"(p));
+    return t;
+}
+
 }  // namespace wv

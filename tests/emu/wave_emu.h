@@ -217,6 +217,17 @@ ACME_DEV double keep(double v) { return v; }
 ACME_DEV int opaque(int v) { return v; }
 ACME_DEV unsigned long long pin(unsigned long long m) { return m; }
 ACME_DEV double sconst(double v) { return v; }
+ACME_DEV double clamp_s(double k, double lo, double hi) { return fmin(fmax(k, lo), hi); }
+struct ExpTab {
+    double v[16];
+    double operator[](int i) const { return v[i]; }
+};
+ACME_DEV ExpTab load_exp_tab() {
+    return ExpTab{{1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+                   1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07,
+                   2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03,
+                   8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, -2100.0, 2100.0}};
+}
 ACME_DEV void sched_fence() {}
 ACME_DEV void lds_add(long long *p, long long v) { *p += v; }
 ACME_DEV void lds_max(long long *p, long long v) { if (v > *p) *p = v; }
