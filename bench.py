@@ -187,7 +187,7 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     from oracle import refpy
     refpy.lib()  # build once before forking
     cores = host_cores()
-    n = len(pots) if pots is not None else len(amp)
+    n = len(pots) if pots is not None else (1 if np.isscalar(amp) else len(amp))   # scalar: identical streams
     pick = np.linspace(0, n - 1, cores * per_core).astype(int)
     sig = np.sin(2 * np.pi * 1000.0 / fs * np.arange(T_cpu))
     jobs = []
@@ -207,7 +207,9 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     return {
         "value": units / slowest, "unit": "circuit-instance*samples/sec", "cores": cores,
         "kind": "port",
-        "sample": f"{len(pick)} instances spread over the sweep x {T_cpu} samples, {per_core} oracle "
+        "sample": (f"{len(pick)} instances spread over the sweep" if n > 1 else
+                   f"{len(pick)} streams of the nominal-component model (the Monte-Carlo instances differ in "
+                   "component values, not in cost)") + f" x {T_cpu} samples, {per_core} oracle "
                   f"streams on each of {cores} cores, slowest worker {slowest:.1f} s "
                   "(C restatement oracle/acme_ref.c, gcc -O2, scalar)",
         "iters_per_sample": sum(r[1] for r in res) / units,

@@ -32,3 +32,14 @@ def test_montecarlo_models_are_seeded_per_rank():
     c = bench.montecarlo_models(1, 3)
     assert np.array_equal(a.d["a"], b.d["a"]) and not np.array_equal(a.d["a"], c.d["a"])
     assert (a.d["nns"], a.d["nqs"], a.d["nps"]) == ([7], [14], [5])
+
+
+def test_cpu_baseline_handles_every_workload_shape():
+    """cpu_baseline with per-instance pots (superover grid), per-instance amplitudes (diode clipper) and
+    one common scalar amplitude (the Monte-Carlo workload, which once crashed here)."""
+    import bench
+    from helpers import load
+    for workload, n in (("superover_grid", 256), ("diodeclipper_sweep", 64), ("superover_montecarlo", 64)):
+        fixture, pots, amp = bench.grid_inputs(workload, 0, 1, n, 64)
+        rec = bench.cpu_baseline(fixture, load(fixture), pots, amp, 64, per_core=1)
+        assert rec["value"] > 0 and rec["kind"] == "port" and rec["iters_per_sample"] >= 1.0
