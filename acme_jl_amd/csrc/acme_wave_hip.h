@@ -175,7 +175,7 @@ ACME_DEV ExpTab load_exp_tab() {
     ExpTab t;
     const double *p = acme_exp_tab;
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(t.lo8), "=s"(t.hi8)
+                 : "=&s"(t.lo8), "=&s"(t.hi8)    // early-clobber: never overlapping the pointer pair
                  : "s"(p));
     return t;
 }
