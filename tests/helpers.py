@@ -16,10 +16,15 @@ FS = 44100
 # runs differ by one Newton step: up to tol / g_min volts, where g_min ~ 2e-3..5e-3 S is the
 # smallest small-signal conductance the residual is measured against (e.g. 1/R + 2C/T of the
 # diode clipper) -> a few 1e-8 V, which then decays through the state.  Hence:
-#   RTOL       hard bound at the reference's default tolerance (solver-tolerance limited)
+#   RTOL       hard bound at the reference's default tolerance (solver-tolerance limited);
+#              measured on MI355X (round 2, gpurun_out/r2a): <= 5e-14 wherever GPU and oracle take
+#              the same Newton paths (identical iteration totals), 1.9e-9 in the one sweep
+#              (birdie_var) where a homotopy episode takes different paths
+#   RTOL_SAME  bound for the cases measured at <= 5e-14 (identical Newton paths)
 #   RTOL_TIGHT bound when both sides run with set_resabstol!(1e-13): stopping-test flips are
 #              then harmless and the two must agree to rounding-level
-RTOL = 2e-7
+RTOL = 2e-8
+RTOL_SAME = 1e-12
 RTOL_TIGHT = 1e-10
 
 

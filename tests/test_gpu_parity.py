@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import RTOL, assert_close, load, oracle_run, sine, sweep_inputs
+from helpers import RTOL, RTOL_SAME, assert_close, load, oracle_run, sine, sweep_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -16,26 +16,30 @@ def runner(hip_lib, model, n, **kw):
     return ModelRunner(model, n, lib=hip_lib, **kw)
 
 
-@pytest.mark.parametrize("name,N,T", [
-    ("diodeclipper", 37, 2048),       # ragged: not a multiple of the 16-instance block
-    ("superover_fixed", 20, 1024),
-    ("superover_var", 33, 1024),
-    ("birdie_fixed", 16, 2048),
-    ("birdie_var", 18, 2048),
-    ("birdie_var_176k", 16, 4096),    # BASELINE config 5's model (fs = 176.4 kHz, variable vol)
-    ("rc_ladder", 5, 512),
-    ("sallenkey", 4, 512),
+# per-case bound = what was measured on MI355X (in the comment) with a margin; the cases at RTOL_SAME
+# take the oracle's Newton paths exactly (iteration totals equal)
+@pytest.mark.parametrize("name,N,T,rtol", [
+    ("diodeclipper", 37, 2048, RTOL_SAME),       # 2.9e-15; ragged: not a multiple of the 16-instance block
+    ("superover_fixed", 20, 1024, RTOL_SAME),    # 4.6e-14
+    ("superover_var", 33, 1024, RTOL_SAME),      # 8.7e-15
+    ("birdie_fixed", 16, 2048, RTOL_SAME),       # 1.8e-14
+    ("birdie_var", 18, 2048, RTOL),              # 1.9e-9: one homotopy episode takes another path
+    ("birdie_var_176k", 16, 4096, 1e-9),         # 5.7e-11; BASELINE config 5's model (fs = 176.4 kHz, variable vol)
+    ("rc_ladder", 5, 512, 1e-14),                # 8.3e-17 (linear)
+    ("sallenkey", 4, 512, 1e-14),                # 3.3e-16 (linear)
 ])
-def test_sweep_matches_oracle(hip_lib, name, N, T):
+def test_sweep_matches_oracle(hip_lib, name, N, T, rtol):
     m = load(name)
     u = sweep_inputs(name, N, T)
     r = runner(hip_lib, m, N)
     y = r.run(u)
     yref, its = oracle_run(m, u)
-    rel = assert_close(y, yref)
+    rel = assert_close(y, yref, rtol=rtol)
     ra = r.report_arrays()
     print(f"{name}: rel err {rel:.2e}, iters gpu {ra['iters_total'].sum()} oracle {its.sum()}")
     assert (ra["first_nonfinite"] < 0).all()
+    if rtol == RTOL_SAME:
+        assert abs(int(ra["iters_total"].sum()) - int(its.sum())) <= 1e-3 * its.sum()
 
 
 def test_config1_doctest_golden(hip_lib):
@@ -90,7 +94,7 @@ def test_analytic_circuits_all_element_kinds(hip_lib):
         r = runner(hip_lib, m, u.shape[0])
         y = r.run(u)
         yref, _ = oracle_run(m, u)
-        rel = assert_close(y, yref)
+        rel = assert_close(y, yref, rtol=RTOL_SAME)     # measured <= 1.2e-14
         print(name, r.kernel_shape(), f"rel err {rel:.2e}")
 
 
