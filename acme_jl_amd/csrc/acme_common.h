@@ -89,7 +89,7 @@ ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int
     int r = 0;
     L.dq = r;     r += np * nx;
     L.eq = r;     r += np * nu;
-    L.fqprev = r; r += np * nz;
+    L.fqprev = r; r += nsub > 1 ? np * nz : 0;   // only read by sub-problems after the first
     L.pexpr = r;  r += nt * np * GROUP;
     L.fqr = r;    r += nt * nn * GROUP;
     L.q0r = r;    r += nt * GROUP;

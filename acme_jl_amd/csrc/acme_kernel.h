@@ -50,17 +50,56 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
     static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY, RARE_ != 0 ? 4 : 3, NSUBr);
+    // samples staged per coalesced u / y transfer: 16, or 8 for the shapes with many inputs (LDS
+    // per block decides whether two blocks fit a CU; a refill exposes ~1 us of HBM latency)
+    static constexpr int CH = NU >= 4 ? CHUNK / 2 : CHUNK;
     // per-instance LDS scratch (doubles): u tile | y tile | report words (int64)
-    static constexpr int UBUF = CHUNK * NU, YBUF = CHUNK * NY, RBUF = 6;
+    static constexpr int UBUF = CH * NU, YBUF = CH * NY, RBUF = 6;
     static constexpr int SCRATCH = (UBUF + YBUF + RBUF + 2) & ~1;
+    // row constants staged in LDS: the kind-by-kind evaluation (RARE) reads all ROWC of them, the
+    // unified rows only UR_SA .. UR_W1
+    static constexpr int RC0 = RARE ? 0 : UR_SA;
+    static constexpr int ROWC_L = RARE ? ROWC : UR_W1 - UR_SA + 1;
+    static constexpr int ROWI_L = (ROWI + 1) / 2;            // doubles holding the ROWI ints of a row
     // persistent state per instance: x | last_p of every sub-problem | last_z of every sub-problem
     static constexpr int STATE = NX + NSUBr * (NP + NN);
-    // per-wave store of the extrapolation origin's  J^-1 * Jp  (nn x np): one slab per matrix
-    // column holding the NN rows of each of the wave's 4 instances back to back (lane r keeps
-    // row r: consecutive addresses, conflict-free ds_read/write_b64).  LDS per block decides
+    // per-wave store of the linearisation at the extrapolation origin, per lane (= per row in the
+    // lanes' order at that moment): the NN elimination multipliers of the row, 1/pivot, the NT Jq
+    // non-zeros and the NT pfull entries of the row -- what the first-order extrapolated start
+    // z0 = last_z - last_J \ (last_Jp (p - last_p))  (src/solvers.jl:209-215) needs, see base_solve.
+    // One slab per slot holding the NN rows of each of the wave's 4 instances back to back (lane r
+    // keeps row r: consecutive addresses, conflict-free ds_read/write_b64).  LDS per block decides
     // whether 2 blocks (= 2 waves/SIMD) fit a CU, so the slabs are packed to NN rows, not 16.
+    // Models with few parameters keep the origin as  J^-1 Jp  (nn x np, row lig per lane) instead:
+    // np augmented columns ride along in the elimination of the accepted iterate and the
+    // extrapolation is one small mat-vec -- cheaper than recording and replaying the elimination
+    // while np is small (measured on MI355X: replaying gains 9 % at np = 11 / nn = 13 and loses
+    // 2 % at 5 / 7, 6 % at 3 / 4, 7 % at 1 / 2, where its nn dependent DPP steps dominate).
+    static constexpr bool MULT = NP >= 8;
+    // Three more choices follow the same split (A/B on MI355X, EXPERIMENTS.md): on the big shape,
+    // whose two waves per SIMD compete for issue slots, fewer instructions win; on the small shapes,
+    // whose launches last as long as ONE wave's dependent chains, shorter chains win.
+    //   FUSE    broadcasts of x_j / z_j / p_j fused into the consuming multiply-add (v_fmac_f64_dpp)
+    //           instead of v_mov_b64_dpp + v_fmac_f64:      big +1.7 %, small -1 .. -3.7 %
+    //   GJHEAD  the scalar head of an elimination step as one fused asm statement with the pivot
+    //           lane handled under a narrowed EXEC instead of four v_cndmask:  big +1 %, small -1 .. -3 %
+    //   SAFE0   step 0 of the elimination with the two DPP wait states built into every fused
+    //           operation (the compiler may copy a row register just before it; it does on the
+    //           small shapes, never on the big one -- tools/dpp_hazard_check.py proves which):  big +1 % without
+    static constexpr bool FUSE = MULT, GJHEAD = MULT, SAFE0 = !MULT;
+    // the row-gathered fq entries of this lane's residual row (NT x NN doubles, used twice per
+    // evaluate!) stay in registers between the rare changes of the lane's row instead of being
+    // re-read from LDS by every evaluate!: since the extrapolation origin moved to the recorded
+    // elimination the headline shape has the registers for it (2 x 39 of 256, no spills)
+#ifndef ACME_FQREG     /* experiment: the register allocator answers with 371 spills (EXPERIMENTS.md) */
+    static constexpr bool FQREG = false;
+#else
+    static constexpr bool FQREG = RARE_ == 0 && NSUB_ == 1 && NN_ * 3 <= 40;
+#endif
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
-    static constexpr int ORIGIN1 = NP * OSTRIDE;              // one sub-problem: J^-1 * Jp
+    static constexpr int OS_MUL = 0, OS_DINV = NN, OS_TV = NN + 1, OS_PF = NN + 1 + NT;
+    static constexpr int OSLOTS = MULT ? NN + 1 + 2 * NT : NP;
+    static constexpr int ORIGIN1 = OSLOTS * OSTRIDE;          // one sub-problem
     static constexpr int ORIGIN = NSUBr * ORIGIN1 + GROUP;
     // solution cache of one sub-problem of one instance.  In LDS: cp[NP][CACHE] | count, head;
     // in HBM the same followed by cz[NN][CACHE] (see acme_common.h)
@@ -71,7 +110,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // the solution caches sit at the end of the block's LDS and are only allocated (and touched) when
     // the batch runs the caching solver
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
-        return (per_instance ? INST_PER_BLOCK : 1) * L.total + NSUBr * (ROWC * GROUP + ROWI * GROUP) +
+        return (per_instance ? INST_PER_BLOCK : 1) * L.total + NSUBr * (ROWC_L * GROUP + ROWI_L * GROUP) +
                INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
 };
@@ -170,37 +209,70 @@ template <int NN> struct RowLU {
     // the lanes whose multiplier exceeded PIVOT_THRESHOLD (or that got a non-finite result):
     // if the calling instance's bits are set the result is discarded and the caller redoes the
     // job after a partially pivoted factorisation (factor) has told it the pivot order.
-    template <int NC>
+    // STORE: the lanes with `keep` record the elimination -- slab[k * OS] = minus this row's
+    // multiplier of step k (0 in the pivot's own lane), slab[NN * OS] = 1/pivot of the row -- so that
+    // the same linear map can later be applied to another right-hand side (apply_stored): that is
+    // all the solver needs of the factorisation at its extrapolation origin.
+    // GJHEAD / SAFE0: see Shape.
+    template <int NC, bool STORE, int OS, bool GJHEAD, bool SAFE0>
     static ACME_DEV unsigned long long solve_inplace(double (&a)[NN > 0 ? NN : 1], double &b,
-                                                     double (&c)[NC > 0 ? NC : 1]) {
+                                                     double (&c)[NC > 0 ? NC : 1], double *slab, bool keep) {
         unsigned long long viol = 0;
         double dinv = 1.0;   // reciprocal of this lane's pivot
+        unsigned long long pivlanes = rows4(1ull);   // lanes holding the pivot row of step k (lig == k)
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
             // a[k] was written by the first fused operation of step k-1; NN-k-1 more of them, the
             // one on b and NC on c[] followed: two are enough wait states for this DPP read
             constexpr bool far_enough = k > 0 && (NN - k + NC >= 2);
-            double piv = wv::bcast16_ordered<k, !far_enough>(a[k]);
-            double inv = wv::recip(piv);
-            dinv = lig_eq<k>() ? inv : dinv;
             // row update  a[j] -= l * (pivot row's a[j]),  b and c[] likewise: fused broadcast-FMAs
             // in program order.  Step 0 reads registers the compiler's own code has just written
             // (SAFE forms); from step 1 on, the previous write of each register is at least two
             // of these statements back (see fmac_bcast_self).
-            const double nlm = lig_eq<k>() ? 0.0 : a[k] * -inv;    // -multiplier of every other row
+            double nlm;                                            // -multiplier of every other row
+            if constexpr (GJHEAD) {
+                // pivot broadcast, reciprocal, minus the multiplier of every other row (0 for the pivot
+                // row itself, which notes 1/pivot in dinv) as one fused statement
+                wv::gj_step_head<k, !far_enough>(a[k], dinv, pivlanes, nlm);
+            } else {
+                const double piv = wv::bcast16_ordered<k, !far_enough>(a[k]);
+                const double inv = wv::recip(piv);
+                dinv = lig_eq<k>() ? inv : dinv;
+                nlm = lig_eq<k>() ? 0.0 : a[k] * -inv;
+            }
+            const unsigned long long big = wv::ballot(fabs(nlm) > PIVOT_THRESHOLD);
+            if constexpr (STORE) {
+                if (keep) slab[k * OS] = nlm;
+            }
             // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
-            viol = wv::pin(viol | (wv::ballot(fabs(nlm) > PIVOT_THRESHOLD) & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
+            viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
+            constexpr bool safe0 = SAFE0 && k == 0;
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
-                wv::fmac_bcast_self<k, k == 0>(a[decltype(jc)::value], nlm);
+                wv::fmac_bcast_self<k, safe0>(a[decltype(jc)::value], nlm);
             });
-            wv::fmac_bcast_self<k, k == 0>(b, nlm);
-            sfor<0, NC>([&](auto jc) ACME_LAMBDA { wv::fmac_bcast_self<k, k == 0>(c[decltype(jc)::value], nlm); });
+            wv::fmac_bcast_self<k, safe0>(b, nlm);
+            sfor<0, NC>([&](auto jc) ACME_LAMBDA { wv::fmac_bcast_self<k, safe0>(c[decltype(jc)::value], nlm); });
         });
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
+        if constexpr (STORE) {
+            if (keep) slab[NN * OS] = dinv;
+        }
         // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
         viol |= wv::ballot(!(b * 0.0 == 0.0));
         return viol;
+    }
+
+    // b <- A^-1 b with the elimination recorded by solve_inplace<.., STORE = true>: the same
+    // operations, in the same order, the right-hand side would have seen riding along as an
+    // augmented column.  Every step reads, through DPP, the register the previous step wrote: the
+    // SAFE forms supply the two wait states.
+    template <int OS> static ACME_DEV void apply_stored(double &b, const double *slab) {
+        sfor<0, NN>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = decltype(kc)::value;
+            wv::fmac_bcast_self<k, true>(b, slab[k * OS]);
+        });
+        b *= slab[NN * OS];
     }
 
     // setlhs! with partial pivoting (first strict maximum, src/solvers.jl:58-78), run only to
@@ -265,8 +337,10 @@ ACME_DEV void eval_row_unified(const RowDesc &rd, const double (&e)[NT], double 
     static_assert(NT >= 3, "unified rows use three q entries");
     const double cA = rd.k[UR_CA - UR_SA], cB = rd.k[UR_CB - UR_SA], dA = rd.k[UR_DA - UR_SA],
                  dB = rd.k[UR_DB - UR_SA], h = rd.k[UR_H - UR_SA];
-    const double g0 = rd.rc[UR_G0 * GROUP], g1 = rd.rc[UR_G1 * GROUP], g2 = rd.rc[UR_G2 * GROUP],
-                 w0 = rd.rc[UR_W0 * GROUP], w1 = rd.rc[UR_W1 * GROUP];
+    // (the non-RARE kernels stage only UR_SA.. in LDS: rd.rc is based at UR_SA)
+    const double g0 = rd.rc[(UR_G0 - UR_SA) * GROUP], g1 = rd.rc[(UR_G1 - UR_SA) * GROUP],
+                 g2 = rd.rc[(UR_G2 - UR_SA) * GROUP], w0 = rd.rc[(UR_W0 - UR_SA) * GROUP],
+                 w1 = rd.rc[(UR_W1 - UR_SA) * GROUP];
     const double hw = h * fma(w1, e[2], w0);
     double r = cA * (exA - 1.0);
     r = fma(cB, exB - 1.0, r);
@@ -427,7 +501,11 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, dou
 // ---------------------------------------------------------------------------------------
 // the per-wave time loop
 // ---------------------------------------------------------------------------------------
-template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
+// MODE_RUN: run! / solve (the hot kernel).  MODE_JAC: one pass that exports every instance's
+// get_extrapolation_jacobian(solver) = -(J \ Jp) at its extrapolation origin (src/solvers.jl:198-201),
+// a separate, small kernel so that its extra registers and code stay out of the hot one.
+enum { MODE_RUN = 0, MODE_JAC = 1 };
+template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
     constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT, NSUB = S::NSUBr;
     constexpr int NNr = NN > 0 ? NN : 1, NPr = NP > 0 ? NP : 1, NQSr = NQS > 0 ? NQS : 1,
@@ -445,9 +523,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
 
     // ---- LDS carve-up -------------------------------------------------------------------
     double *lds_img = lds;
-    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;        // [NSUB][ROWC*16]
-    int *lds_rowi = (int *)(lds_rowc + NSUB * ROWC * GROUP);                       // [NSUB][ROWI*16]
-    double *lds_scr = lds_rowc + NSUB * (ROWC * GROUP + ROWI * GROUP);
+    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;        // [NSUB][ROWC_L*16]
+    int *lds_rowi = (int *)(lds_rowc + NSUB * S::ROWC_L * GROUP);                  // [NSUB][ROWI*16]
+    double *lds_scr = lds_rowc + NSUB * (S::ROWC_L * GROUP + S::ROWI_L * GROUP);
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
     double *const ojp0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;
     double *const cache0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + WAVES_PER_BLOCK * S::ORIGIN + gib * S::CACHEI;
@@ -469,7 +547,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 for (int i = tid; i < L.total; i += nthreads) lds_img[g * L.total + i] = src[i];
             }
         }
-        for (int i = tid; i < NSUB * ROWC * GROUP; i += nthreads) lds_rowc[i] = A.rowc[i];
+        for (int s = 0; s < NSUB; ++s)     // only the constants this shape's row evaluation reads
+            for (int i = tid; i < S::ROWC_L * GROUP; i += nthreads)
+                lds_rowc[s * S::ROWC_L * GROUP + i] = A.rowc[(s * ROWC + S::RC0) * GROUP + i];
         for (int i = tid; i < NSUB * ROWI * GROUP; i += nthreads) lds_rowi[i] = A.rowi[i];
     }
     wv::block_sync();
@@ -482,6 +562,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // zero this instance's scratch once: with a padded shape (nu_io < NU) some u-tile entries
     // are read but never written
     for (int i = lig; i < S::SCRATCH; i += GROUP) ubuf[i] = 0.0;
+    // ... and this wave's origin slabs: a linearisation that fails before anything was recorded
+    // must leave a harmless (zero) extrapolation behind, not whatever the LDS held
+    for (int i = lane; i < S::ORIGIN; i += 64) lds_scr[INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + i] = 0.0;
     // the solution caches live in HBM between launches
     if (A.solver == SOLVER_CACHING_HOMOTOPY && valid)
         for (int s = 0; s < S::NSUBr; ++s)
@@ -494,15 +577,24 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // lanes ADOPT the pivoted order, so the next factorisation finds its pivots in place.
     int rowid = lig;
     RowDesc rd;
+    double fqreg[S::FQREG ? NT : 1][S::FQREG ? NNr : 1];
     auto load_rowdesc = [&]() ACME_LAMBDA {
         rd.kind = (lig < NN) ? rowi_s[0 * GROUP + rowid] : RK_NONE;
         rd.erow = rowi_s[1 * GROUP + rowid];
         rd.flags = rowi_s[2 * GROUP + rowid];
-        rd.rc = rowc_s + rowid;
+        rd.rc = rowc_s + rowid;            // rc[c * GROUP] = row constant RC0 + c
         // register-cached constants: the kind-by-kind evaluation (RARE shapes) wants rc[0..7],
         // the unified rows sA sB cA cB dA dB h
-        constexpr int K0 = S::RARE ? 0 : UR_SA;
-        sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[(K0 + decltype(c_)::value) * GROUP]; });
+        sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
+        if constexpr (S::FQREG) {
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    fqreg[t][j] = Ms[L.fqr + (t * NN + j) * GROUP + rowid];
+                });
+            });
+        }
     };
     load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
@@ -511,8 +603,9 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     double x[NXSr];      // state vector, element s*16+lig
     double lp = 0.0;     // extrapolation origin: last_p[lig]
     double lz = 0.0;     //                       last_z[lig]
-    // the origin's  -dz/dp = last_J^-1 * last_Jp  lives in LDS (ojp[j*OS], row lig): it is all
-    // the first-order extrapolated start (src/solvers.jl:209-215) needs
+    // the origin's linearisation (elimination multipliers, 1/pivot, Jq non-zeros, pfull entries of
+    // row lig) lives in LDS (ojp[slot * OS]): all the first-order extrapolated start
+    // (src/solvers.jl:209-215) needs
     double z = 0.0;      // current iterate z[lig]
     double pf[NT];       // (q0 + pexp*p) at the q rows rd.tc[] of this lane's residual row
     // per-row results of the latest evaluate!
@@ -532,11 +625,13 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // the sub-problem being solved
     double lps[NSUB], lzs[NSUB], zs[NSUB];
     int rowids[NSUB];
+    bool stales[NSUB];
     sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         lps[s] = (NP > 0 && valid && lig < NP) ? st[NX + s * NP + lig] : 0.0;
         lzs[s] = (NN > 0 && valid && lig < NN) ? st[NX + NSUB * NP + s * NN + lig] : 0.0;
         zs[s] = 0.0;
+        stales[s] = true;
         rowids[s] = valid ? A.roworder[(inst * NSUB + s) * GROUP + lig] : lig;
     });
     const int nsub = (NN > 0) ? A.nsub : 0;
@@ -562,16 +657,22 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // ---- helpers ------------------------------------------------------------------------
     // pfull <- q0 + pexp*p   (set_p closure, src/ACME.jl:237-243), only the entries this
     // lane's row needs
+    // (FUSE: p_j reaches the lanes through the DPP operand of the multiply-add itself, see fmac_bcast)
     auto set_p = [&](double p) ACME_LAMBDA {
         double pb[NPr];
-        sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
-        wv::sched_fence();
+        if constexpr (!S::FUSE) {
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
+            wv::sched_fence();
+        } else {
+            wv::dpp_wait();      // p may be fresh from the homotopy bookkeeping
+        }
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
             double acc = Ms[L.q0r + t * GROUP + rowid];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                acc = fma(Ms[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
+                if constexpr (!S::FUSE) acc = fma(Ms[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
+                else wv::fmac_bcast<j>(acc, p, Ms[L.pexpr + (t * NP + j) * GROUP + rowid]);
             });
             pf[t] = acc;
             wv::sched_fence();   // bound the number of LDS loads in flight (register pressure)
@@ -585,27 +686,43 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         // q[tc[t]] = pfull + fq*z for the (at most NT) q entries this row depends on: every
         // lane forms its own, so no cross-lane exchange of q is needed
         double zb[NNr];
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA { zb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(zz); });
+        if constexpr (!S::FUSE)
+            sfor<0, NN>([&](auto jc) ACME_LAMBDA { zb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(zz); });
         // this row's fq entries (used twice: q = pf + fq*z here, J = Jq*fq below)
         double fqv[NT][NNr];
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
             sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                fqv[t][j] = Ms[L.fqr + (t * NN + j) * GROUP + rowid];
+                if constexpr (S::FQREG) fqv[t][j] = fqreg[t][j];
+                else fqv[t][j] = Ms[L.fqr + (t * NN + j) * GROUP + rowid];
             });
         });
-        wv::sched_fence();
+        if constexpr (!S::FQREG) wv::sched_fence();
         double e[NT];
-        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
-            constexpr int t = decltype(tc_)::value;
-            double acc = pf[t];
-            sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                acc = fma(fqv[t][j], zb[j], acc);
+        if constexpr (!S::FUSE) {
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                double acc = pf[t];
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    acc = fma(fqv[t][j], zb[j], acc);
+                });
+                e[t] = acc;
             });
-            e[t] = acc;
-        });
+        } else {
+            // z_j reaches the lanes through the DPP operand of the multiply-add; zz is the iterate
+            // the caller updated a few instructions before
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
+            wv::dpp_wait();
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    wv::fmac_bcast<j>(e[t], zz, fqv[t][j]);
+                });
+            });
+        }
         ACME_T2(TB_E1);
         // hoisted exponentials: diode exp(v/(eta vT)), BJT exp(vE/..), exp(vC/..)
         double exA, exB;
@@ -637,9 +754,15 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         });
         // non-finite anywhere in this instance's res / J ?  (src/solvers.jl:220)  0*x is 0 for
         // finite x and NaN otherwise; a chain of 4-byte v_fmac (code size matters more here than
-        // the length of the dependency chain)
+        // the length of the dependency chain).  J = Jq fq with finite constants fq: it is finite when
+        // the row's Jq non-zeros are, short of an overflow of their products with fq -- which turns the
+        // elimination's result non-finite and ends the solve the same way (solve_inplace checks).
         double chk = res * 0.0;
+#ifdef ACME_FINITE_FULL
         sfor<0, NN>([&](auto jc) ACME_LAMBDA { chk = fma(a[decltype(jc)::value], 0.0, chk); });
+#else
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA { chk = fma(tv[decltype(tc_)::value], 0.0, chk); });
+#endif
         unsigned long long bad = wv::ballot(lig < NN && !(chk == 0.0));
         return ((bad >> (grp * GROUP)) & 0xFFFFull) == 0ull;
     };
@@ -672,14 +795,19 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // One Newton linearisation at z: evaluate! (res, J), then solve J dz = res by in-place
     // Gauss-Jordan.  An iterate whose residual is already below tol is going to be accepted and
     // become the new extrapolation origin (hasconverged looks at the residual alone,
-    // src/solvers.jl:203,225-233); for it -- `want`, or `force` -- the columns of Jp ride along
-    // and the instance's lanes write their rows of J^-1*Jp to the origin slab
-    // (set_extrapolation_origin, src/solvers.jl:191-196).  If the in-place pivots were not the
-    // maxima (a few % of the calls) the retry loop evaluates again, runs the reference's
-    // partially pivoted LU to learn the pivot order, lets the lanes adopt it, evaluates in the
-    // new order and eliminates again.  evaluate / pivot_order / solve_inplace each have ONE call
+    // src/solvers.jl:203,225-233); for it -- `want`, or `force` -- the instance's lanes record the
+    // elimination (their multipliers and 1/pivot), the row's Jq non-zeros and its pfull entries in
+    // the origin slab (set_extrapolation_origin, src/solvers.jl:191-196: the reference keeps the
+    // factors and Jp there; Jp (p' - p) = Jq (pexp p' - pexp p) needs only Jq and pfull).  If the
+    // in-place pivots were not the maxima (a few % of the calls) the retry loop evaluates again,
+    // runs the reference's partially pivoted LU to learn the pivot order, lets the lanes adopt it,
+    // evaluates in the new order and eliminates again.  evaluate / pivot_order each have ONE call
     // site (code size, registers); `phase` is opaque so that the optimiser does not clone the
     // body per phase.  finite: res and J finite; ok: J non-singular; small: |res| < tol.
+    // `stale`: the slab no longer describes the origin (lp, lz) in the lanes' current order -- an
+    // instance changed its row order without storing a new origin, or a recorded elimination was
+    // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
+    bool stale = true;
     auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
         ok = true;
         int phase = 0;   // 0: first try   1: learn the pivot order   2: retry in the new order
@@ -695,6 +823,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 ok = relearn ? okp : true;
                 orig = relearn ? orig : lig;
                 adopt();
+                if constexpr (S::MULT) stale = stale || relearn;   // the recorded elimination is per row order
                 phase = 2;
                 ACME_T(TB_PIVOT);
                 continue;
@@ -705,16 +834,20 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
             const bool want = force || (act && finite && small);
             unsigned long long viol;
+            double none[1] = {0.0};
             double jp[NPr];
             dz = res;
-            const bool with_jp = wv::ballot(want) != 0ull;
-            if (with_jp) {
-                calc_jp(jp);
-                viol = LU::template solve_inplace<NP>(a, dz, jp);
+            const bool recording = wv::ballot(want) != 0ull;
+            if (recording) {
+                if constexpr (S::MULT) {
+                    viol = LU::template solve_inplace<0, true, OS, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, want && lig < NN);
+                } else {       // the columns of Jp ride along: jp <- J^-1 Jp
+                    calc_jp(jp);
+                    viol = LU::template solve_inplace<NP, false, OS, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false);
+                }
                 ACME_T(TB_GJP);
             } else {
-                double none[1] = {0.0};
-                viol = LU::template solve_inplace<0>(a, dz, none);
+                viol = LU::template solve_inplace<0, false, OS, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, false);
                 ACME_T(TB_GJ0);
             }
             viol &= wv::ballot(act || force);   // the other instances' results are not used
@@ -725,8 +858,23 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 continue;
             }
             ok = ok && !mine;
-            if (with_jp && want && !mine && lig < NN)   // per-lane predicated LDS stores
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
+            if (recording) {
+                if (want && !mine && lig < NN) {   // per-lane predicated LDS stores
+                    if constexpr (S::MULT) {
+                        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                            constexpr int t = decltype(tc_)::value;
+                            ojp[(S::OS_TV + t) * OS] = tv[t];
+                            ojp[(S::OS_PF + t) * OS] = pf[t];
+                        });
+                    } else {
+                        sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
+                    }
+                }
+                // MULT: recorded and kept -> the slab is the origin-to-be; recorded but unusable -> it
+                // is nothing.  Otherwise the slab is only written when the result is kept.
+                if constexpr (S::MULT) stale = want ? mine : stale;
+                else stale = stale && !(want && !mine);
+            }
             ACME_T(TB_STORE);
             break;
         }
@@ -736,7 +884,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     auto enter_sub = [&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         Ms = M + L.sub0 + s * L.sub_stride;
-        rowc_s = lds_rowc + s * ROWC * GROUP;
+        rowc_s = lds_rowc + s * S::ROWC_L * GROUP;
         rowi_s = lds_rowi + s * ROWI * GROUP;
         ojp = ojp0 + s * S::ORIGIN1;
         cch = cache0 + s * S::CACHE1;
@@ -744,6 +892,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         lp = lps[s];
         lz = lzs[s];
         rowid = rowids[s];
+        stale = stales[s];
         load_rowdesc();
     };
     auto leave_sub = [&](auto sc) ACME_LAMBDA {
@@ -751,27 +900,37 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         lps[s] = lp;
         lzs[s] = lz;
         rowids[s] = rowid;
+        stales[s] = stale;
     };
 
     // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196): the factors and Jp at the
     // origin are recomputed from (p, z), so only (p, z) has to persist in HBM.  That happens
-    // lazily, before the first base solve of each sub-problem (`fresh`), through the same code as a
-    // change of origin on a solution-cache hit (cached_solve).
-    bool fresh[NSUB > 0 ? NSUB : 1];
-    sfor<0, NSUB>([&](auto sc) ACME_LAMBDA { fresh[decltype(sc)::value] = true; });
+    // lazily, before the first base solve of each sub-problem (`stale` starts true), through the same
+    // code as a change of origin on a solution-cache hit (cached_solve).
     if (S::NSUB == 1) enter_sub(std::integral_constant<int, 0>{});   // stays entered for the whole launch
 
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
     // returns hasconverged, leaves needediterations in `its`.
     auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
         set_p(target);
-        // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215)
-        double dp = target - lp;
+        // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215).  Row r of
+        // last_Jp (p - last_p) is  sum_t Jq[r, tc_t] (pfull(p) - pfull(last_p))[tc_t]  (Jp = Jq pexp,
+        // src/ACME.jl:246-251): the origin's Jq non-zeros times the change of this row's pfull
+        // entries, which set_p has just formed; then the origin's recorded elimination.
         double t = 0.0;
-        sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            t = fma(ojp[j * OS], wv::bcast16<j>(dp), t);
-        });
+        if constexpr (S::MULT) {
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int tt = decltype(tc_)::value;
+                t = fma(ojp[(S::OS_TV + tt) * OS], pf[tt] - ojp[(S::OS_PF + tt) * OS], t);
+            });
+            LU::template apply_stored<OS>(t, ojp);
+        } else {       // the slab holds J^-1 Jp, row lig
+            const double dp = target - lp;
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                t = fma(ojp[j * OS], wv::bcast16<j>(dp), t);
+            });
+        }
         z = sel(need, lz - t, z);
         bool act = need, conv = false, accepted = false;
         its = 0;
@@ -809,20 +968,31 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     // without a cache, 4.5 with 8 entries, 3.02 with 16, 3.00 with 32 and 3.02 unbounded -- and a
     // launch lasts as long as its slowest wave.
     const bool caching = A.solver == SOLVER_CACHING_HOMOTOPY;
-    auto cached_solve = [&](double target, bool need, bool first, int &its) ACME_LAMBDA -> bool {
+    auto cached_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
         double *cp = cch, *cz = czg;
         int *meta = reinterpret_cast<int *>(cch + NP * CACHE);   // count, head
-        bool reorig = first;        // (lp, lz) not linearised yet: launch start, or new origin below
+        bool reorig = stale;        // (lp, lz) not linearised (in this row order): launch start, ..., or new origin below
         if (caching) {
             const int count = meta[0];
             const double dl = (lig < NP) ? target - lp : 0.0;
             const double best = wv::allsum16(dl * dl);
             double d = 0.0;
-            sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                const double t = cp[j * CACHE + (lig & (CACHE - 1))] - wv::bcast16<j>(target);
-                d = fma(t, t, d);
-            });
+            if constexpr (!S::FUSE) {
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    const double t = cp[j * CACHE + (lig & (CACHE - 1))] - wv::bcast16<j>(target);
+                    d = fma(t, t, d);
+                });
+            } else {   // cp_j - p_j as a fused broadcast multiply-add with -1 (exact), then the square
+                const double m1 = wv::keep(-1.0);
+                wv::dpp_wait();
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    double t = cp[j * CACHE + (lig & (CACHE - 1))];
+                    wv::fmac_bcast<j>(t, target, m1);
+                    d = fma(t, t, d);
+                });
+            }
             d = (lig < count) ? d : (double)INFINITY;
             const double m = wv::allmin16(d);
             const unsigned long long bal = wv::ballot(d == m);
@@ -889,7 +1059,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     auto fetch_u = [&](long long n0) ACME_LAMBDA {
         const double *ug = A.u + ((valid ? inst : 0) * T + n0) * nu_io;
         long long cnt = T - n0;
-        if (cnt > CHUNK) cnt = CHUNK;
+        if (cnt > S::CH) cnt = S::CH;
         sfor<0, NU>([&](auto ic) ACME_LAMBDA {
             constexpr int i = decltype(ic)::value;
             int e = lig + GROUP * i;
@@ -901,7 +1071,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         sfor<0, NU>([&](auto ic) ACME_LAMBDA {
             constexpr int i = decltype(ic)::value;
             int e = lig + GROUP * i;
-            if (e < CHUNK * nu_io) ubuf[(e / nu_io) * NU + (e % nu_io)] = upre[i];
+            if (e < S::CH * nu_io) ubuf[(e / nu_io) * NU + (e % nu_io)] = upre[i];
         });
         wv::wave_fence();
     };
@@ -910,8 +1080,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
         stage_u();
     }
 
-    for (long long n0 = 0; n0 < T; n0 += CHUNK) {
-        int cnt = (int)((T - n0 < CHUNK) ? (T - n0) : CHUNK);
+    for (long long n0 = 0; n0 < T; n0 += S::CH) {
+        int cnt = (int)((T - n0 < S::CH) ? (T - n0) : S::CH);
         for (int m = 0; m < cnt; ++m) {
             const long long n = A.sample_base + n0 + m;
             ACME_T(TB_POST);
@@ -927,8 +1097,12 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 double p = 0.0;
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
-                    p = fma(Ms[L.dq + j * NP + lig], xj, p);
+                    if constexpr (!S::FUSE) {
+                        double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
+                        p = fma(Ms[L.dq + j * NP + lig], xj, p);
+                    } else {
+                        wv::fmac_bcast<j % GROUP>(p, x[j / GROUP], Ms[L.dq + j * NP + lig]);   // x: last sample's update
+                    }
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
@@ -938,7 +1112,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     constexpr int sp = decltype(pc)::value;
                     sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                         constexpr int j = decltype(jc)::value;
-                        p = fma(Ms[L.fqprev + (sp * NN + j) * NP + lig], wv::bcast16<j>(zs[sp]), p);
+                        if constexpr (!S::FUSE) p = fma(Ms[L.fqprev + (sp * NN + j) * NP + lig], wv::bcast16<j>(zs[sp]), p);
+                        else wv::fmac_bcast<j>(p, zs[sp], Ms[L.fqprev + (sp * NN + j) * NP + lig]);
                     });
                 });
                 if (solve_mode) p = (valid && lig < A.np_io) ? A.p_in[inst * A.np_io + lig] : 0.0;
@@ -951,8 +1126,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 ACME_T(TB_PRE);
                 while (wv::ballot(need)) {
                     int its;
-                    bool c = cached_solve(target, need, fresh[s], its);
-                    fresh[s] = false;
+                    bool c = cached_solve(target, need, its);
                     ACME_DBG("hom step lane %d need %d mode %d ha %.17g hbest %.17g conv %d its %d", lane, (int)need, mode, ha, hbest, (int)c, its);
                     its_sample += need ? its : 0;
                     conv = need ? c : conv;
@@ -1012,7 +1186,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 if (S::NSUB > 1) leave_sub(sc);
             });
             if (solve_mode) continue;
-            const bool refill = NU > 0 && m == cnt - 1 && n0 + CHUNK < T;
+            const bool refill = NU > 0 && m == cnt - 1 && n0 + S::CH < T;
             const bool live = !dead;
             wv::sched_fence();
             constexpr int LD = NX + NY;
@@ -1022,9 +1196,11 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                 // [a b c x0], lanes NX .. NX+NY-1 the rows of [dy ey fy y0] (same operations per row
                 // as two separate passes, half the instructions and LDS reads)
                 double acc = M[L.x0 + lig];
+                if constexpr (S::FUSE) wv::dpp_wait();    // zs[] was selected just above
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    acc = fma(M[L.a + j * LD + lig], wv::bcast16<j>(x[0]), acc);
+                    if constexpr (!S::FUSE) acc = fma(M[L.a + j * LD + lig], wv::bcast16<j>(x[0]), acc);
+                    else wv::fmac_bcast<j>(acc, x[0], M[L.a + j * LD + lig]);
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
@@ -1034,7 +1210,8 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
                     constexpr int s = decltype(sc)::value;
                     sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                         constexpr int j = decltype(jc)::value;
-                        acc = fma(M[L.c + (s * NN + j) * LD + lig], wv::bcast16<j>(zs[s]), acc);
+                        if constexpr (!S::FUSE) acc = fma(M[L.c + (s * NN + j) * LD + lig], wv::bcast16<j>(zs[s]), acc);
+                        else wv::fmac_bcast<j>(acc, zs[s], M[L.c + (s * NN + j) * LD + lig]);
                     });
                 });
                 if (NY > 0 && lig >= NX && lig < NX + NY) ybuf[m * NY + lig - NX] = live ? acc : (double)NAN;
@@ -1102,7 +1279,7 @@ template <class S> ACME_DEV void wave_main(const KArgs &A, double *lds) {
             }
             }
             if (refill) {     // next u tile: this sample's y/x update was the last reader of the old one
-                fetch_u(n0 + CHUNK);
+                fetch_u(n0 + S::CH);
                 stage_u();
             }
         }

@@ -8,6 +8,10 @@
 // the np(model,k) pins of test/runtests.jl:699,724,734,744,777).
 #pragma once
 // clang-format off
+#ifdef ACME_DEV_SHAPES   /* developer builds (tools/isa.sh): only the headline shape, compiles in seconds */
+#define ACME_SHAPES(X)                                                                     \
+    X(13, 29, 11, 11, 4, 1, 0, 1)
+#else
 #define ACME_SHAPES(X)                                                                     \
     X( 2,  4,  1,  1, 1, 1, 0, 1)  /* examples/diodeclipper.jl                          */ \
     X( 7, 14,  5, 11, 1, 1, 0, 1)  /* examples/superover.jl, fixed potentiometers       */ \
@@ -21,3 +25,4 @@
     X( 4, 12,  4, 16, 4, 4, 1, 4)  /* decomposed nonlinearity: up to 4 small sub-problems */ \
     X( 8, 24,  8, 16, 4, 4, 1, 4)  /* decomposed nonlinearity: up to 4 medium sub-problems */
 // clang-format on
+#endif

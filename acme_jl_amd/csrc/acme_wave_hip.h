@@ -46,6 +46,75 @@ template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mu
         asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
                      : "+v"(acc) : "v"(mul), "n"(K));
 }
+// acc += (lane K of src's row) * mul  with src another register than acc: the broadcast of x_j /
+// z_j / p_j fused into the multiply-add that consumes it (one instruction instead of v_mov_b64_dpp +
+// v_fmac_f64, and no register for the broadcast value).  src must not have been written by a VALU
+// instruction within the two preceding wait states: callers pass values produced well before, and
+// tools/dpp_hazard_check.py proves it for every DPP instruction of the built code object.
+template <int K> ACME_DEV void fmac_bcast(double &acc, double src, double mul) {
+    // NOT volatile: the compiler may interleave these with the LDS reads that feed them (as ordered
+    // statements they made the wave wait for whole batches of loads: -4 % instead of +1.7 %)
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+// two wait states before a run of fmac_bcast statements whose source may have just been produced
+ACME_DEV void dpp_wait() { asm volatile("s_nop 1"); }
+// Pivot-lane bookkeeping of one elimination step, for the lanes of `mask` only (a wave-uniform
+// lane mask): dinv = inv, nlm = 0.  Two moves under a narrowed EXEC instead of four v_cndmask.
+// EXEC is written by SALU instructions here, which DPP instructions do not have to wait for.
+ACME_DEV void pivot_lane_moves(unsigned long long mask, double &dinv, double inv, double &nlm) {
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_mov_b64 %[d], %[i]\n\tv_mov_b64 %[n], 0\n\ts_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(save), [d] "+v"(dinv), [n] "+v"(nlm) : [m] "s"(mask), [i] "v"(inv) : "scc");
+}
+// next step's pivot-lane mask: one s_lshl_b64 on a live scalar pair instead of two s_mov_b32 of a
+// fresh 64-bit literal
+ACME_DEV unsigned long long mask_shl1(unsigned long long m) {
+    asm("s_lshl_b64 %0, %0, 1" : "+s"(m) : : "scc");
+    return m;
+}
+
+// The scalar head of one Gauss-Jordan step as ONE statement (the compiler brackets every inline-asm
+// statement with defensive s_nop's; fused, the step costs 14 issue slots instead of 20):
+//   piv  = row_newbcast:K of ak                       (pivot, to every lane of the row)
+//   inv  = 1/piv                                      (v_rcp_f64 + the cubic refinement of recip())
+//   nlm  = -ak * inv   (0 in the lanes of pivlanes)   (minus the multiplier of every other row)
+//   dinv = inv         (in the lanes of pivlanes)     (the pivot row remembers 1/pivot)
+//   pivlanes <<= 1 for the next step.  (The |nlm| > 4 ballot stays outside: as an output of a
+//   statement that also has vector outputs the compiler would treat the mask as divergent.)
+// SAFE: ak may have been written within the two preceding wait states.  Inside: one wait state
+// between the transcendental v_rcp_f64 and its first use; EXEC is only written by SALU
+// instructions, which neither DPP nor VALU instructions have to wait for.
+template <int K, bool SAFE>
+ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm) {
+    double piv, inv, e;
+    unsigned long long sv;
+#define ACME_GJ_HEAD_BODY                                                                          \
+        "v_mov_b64_dpp %[piv], %[ak] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"          \
+        "v_rcp_f64_e32 %[inv], %[piv]\n\t"                                                       \
+        "s_nop 0\n\t"                                                                            \
+        "v_fma_f64 %[e], -%[piv], %[inv], 1.0\n\t"                                               \
+        "v_fmac_f64_e32 %[e], %[e], %[e]\n\t"                                                    \
+        "v_fmac_f64_e32 %[inv], %[inv], %[e]\n\t"                                                \
+        "v_mul_f64 %[nlm], %[ak], -%[inv]\n\t"                                                   \
+        "s_and_saveexec_b64 %[sv], %[m]\n\t"                                                     \
+        "v_mov_b64 %[dinv], %[inv]\n\t"                                                          \
+        "v_mov_b64 %[nlm], 0\n\t"                                                                \
+        "s_mov_b64 exec, %[sv]\n\t"                                                              \
+        "s_lshl_b64 %[m], %[m], 1"
+    if (SAFE)
+        asm volatile("s_nop 1\n\t" ACME_GJ_HEAD_BODY
+                     : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),
+                       [sv] "=&s"(sv), [m] "+s"(pivlanes)
+                     : [ak] "v"(ak), [k] "n"(K) : "scc");
+    else
+        asm volatile(ACME_GJ_HEAD_BODY
+                     : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),
+                       [sv] "=&s"(sv), [m] "+s"(pivlanes)
+                     : [ak] "v"(ak), [k] "n"(K) : "scc");
+#undef ACME_GJ_HEAD_BODY
+}
+
 // bcast16<K> as a volatile statement (ordered with the fused operations); SAFE: with the two wait
 // states built in
 template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) {

@@ -174,6 +174,22 @@ template <int K> ACME_DEV int bcast16(int v) {
 }
 template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mul) { acc = fma(bcast16<K>(acc), mul, acc); }
 template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) { return bcast16<K>(v); }
+template <int K> ACME_DEV void fmac_bcast(double &acc, double src, double mul) { acc = fma(bcast16<K>(src), mul, acc); }
+ACME_DEV void dpp_wait() {}
+ACME_DEV bool lanes(unsigned long long mask);
+ACME_DEV void pivot_lane_moves(unsigned long long mask, double &dinv, double inv, double &nlm) {
+    if (lanes(mask)) { dinv = inv; nlm = 0.0; }
+}
+ACME_DEV unsigned long long mask_shl1(unsigned long long m) { return m << 1; }
+ACME_DEV double recip(double d);
+template <int K, bool SAFE>
+ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm) {
+    const double piv = bcast16<K>(ak);
+    const double inv = recip(piv);
+    nlm = ak * -inv;
+    if (lanes(pivlanes)) { dinv = inv; nlm = 0.0; }
+    pivlanes <<= 1;
+}
 template <int R> ACME_DEV double ror16(double v) {
     int lane = tid() & 63;
     // row_ror:R -- lane i receives the value of lane (i - R) mod 16 of its row

@@ -43,3 +43,29 @@ def test_cpu_baseline_handles_every_workload_shape():
         fixture, pots, amp = bench.grid_inputs(workload, 0, 1, n, 64)
         rec = bench.cpu_baseline(fixture, load(fixture), pots, amp, 64, per_core=1)
         assert rec["value"] > 0 and rec["kind"] == "port" and rec["iters_per_sample"] >= 1.0
+
+
+def test_drive_one_corner_is_singular():
+    """Why bench.py's grid takes drive = i/32 instead of SURVEY 8(d)'s linspace(0, 1, 32): with the
+    drive pot at exactly 1.0 its shorted leg (pins 2 and 3 of p1 share a node,
+    examples/superover.jl:37) has 0 Ohm across a short -- the current through it is indeterminate
+    and the variable-pot model's Jacobian is singular.  The oracle (the reference's algorithm)
+    then fails to converge on practically every sample (one warning and ~900 Newton iterations per
+    sample), with either solver stack; at drive = 31/32 and at drive = 0 it converges in a handful.
+    (The reference's own test touches the corner for one sample only: the pot ramps of
+    test/runtests.jl:778 start at 1.0.)"""
+    from helpers import load, sine
+    from oracle.refpy import RefRunner
+    from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
+    T = 60
+    for solver in (HomotopySolver, CachingHomotopySolver):
+        m = load("superover_var", solver)
+        for drive, singular in ((1.0, True), (31 / 32, False), (0.0, False)):
+            u = np.zeros((4, T))
+            u[0], u[1], u[2], u[3] = sine(T), drive, 0.5, 0.5
+            r = RefRunner(m)
+            r.run(u)
+            if singular:
+                assert r.report.n_warn >= T - 5 and r.report.iters_total > 300 * T
+            else:
+                assert r.report.n_warn == 0 and r.report.iters_total < 20 * T
