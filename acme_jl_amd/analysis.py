@@ -78,10 +78,9 @@ def linearize(model, usteady=None, lib=None, device=None):
     linear ``DiscreteModel`` around the steady state for the constant input ``usteady``.
 
     The two nonlinear solves (steady state at tolerance 1e-15, then ``solve(solver, psteady)`` with
-    the model's own solver settings) run on the GPU; ``get_extrapolation_jacobian`` = -J \\ Jp at
-    the solution and the assembly of the linear model are a handful of small dense products on the
-    host, as they are LAPACK calls in the reference."""
-    from .hostsolve import eval_table
+    the model's own solver settings) and ``get_extrapolation_jacobian`` = -J \\ Jp at the solution
+    (``acme_batch_get_extrapolation_jacobian``) run on the GPU; the assembly of the linear model is a
+    handful of small dense products on the host, as they are BLAS calls in the reference."""
     if len(model.subs) > 1:
         raise AcmeError("linearize on the GPU supports a single nonlinear sub-problem")
     u = np.zeros(model.nu) if usteady is None else np.asarray(usteady, dtype=np.float64)
@@ -96,10 +95,9 @@ def linearize(model, usteady=None, lib=None, device=None):
         if not conv.all():
             raise ValueError(f"Cannot linearize because no solution found at p={ps}")
         z = z[0]
-        q = s.q0 + s.pexp @ ps + s.fq @ z
-        _, jq = eval_table(s.table, q.tolist(), s.nn, s.nq)
-        jq = np.asarray(jq)
-        dzdp = -np.linalg.solve(jq @ s.fq, jq @ s.pexp)          # get_extrapolation_jacobian
+        dzdp = r.get_extrapolation_jacobian()[0]       # -(J \ Jp) at (ps, z): the solve just made it the origin
+        if not np.isfinite(dzdp).all():
+            raise ValueError(f"Cannot linearize: singular Jacobian at p={ps}")
         x0 += model.c @ (z - dzdp @ ps)
         a += model.c @ dzdp @ s.dq
         b += model.c @ dzdp @ s.eq

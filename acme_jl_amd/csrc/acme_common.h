@@ -137,7 +137,8 @@ struct KArgs {
     double *z_out;           // [n_inst][nn_io]
     int *conv_out, *iters_out;
     int np_io, nn_io;
-    int solve_sub;           // sub-problem acme_batch_solve addresses
+    double *jac_out;         // MODE_JAC kernels: [n_inst][np_io][nn_io] = -(J \ Jp) at the origin of solve_sub
+    int solve_sub;           // sub-problem acme_batch_solve / the Jacobian export addresses
     int nsub;                // actual number of sub-problems (<= the shape's NSUB)
 };
 

@@ -28,12 +28,20 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_run_kernel(KArgs
     wave_main<S>(A, acme_lds);
 }
 
+// the small companion kernel: get_extrapolation_jacobian for every instance (wave_main MODE_JAC)
+template <class S>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_jac_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S, MODE_JAC>(A, acme_lds);
+}
+
 struct KernelEntry {
     Dims d;
-    const void *fn;
+    const void *fn, *fn_jac;
     int lds_shared, lds_per_inst;  // doubles
     int state;                     // doubles of state per instance
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
+    int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
 };
 
 template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
@@ -41,13 +49,28 @@ template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t
     return (int)hipGetLastError();
 }
 
+template <class S> static int launch_jac_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    if constexpr (S::NN > 0) {
+        hipLaunchKernelGGL(acme_jac_kernel<S>, dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+        return (int)hipGetLastError();
+    } else {
+        return (int)hipErrorInvalidValue;      // linear models have no nonlinear solver
+    }
+}
+template <class S> static const void *jac_fn() {
+    if constexpr (S::NN > 0) return (const void *)acme_jac_kernel<S>;
+    else return nullptr;
+}
+
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
 #define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
     KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>, \
+                jac_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                             \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
-                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
+                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                        \
+                &launch_jac_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };

@@ -1034,6 +1034,51 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         return c;
     };
 
+    // ---- MODE_JAC: get_extrapolation_jacobian for every instance ---------------------------
+    // -(J \\ Jp) at the extrapolation origin (last_p, last_z) of sub-problem A.solve_sub
+    // (src/solvers.jl:198-201; used by linearize, :407-414): re-linearise there exactly like
+    // set_extrapolation_origin does (:183-196) with the columns of Jp riding along in the
+    // elimination, in the reference's pivot order if the rows' current order fails the threshold.
+    // Nothing of the batch's state is modified.
+    if constexpr (MODE == MODE_JAC) {
+        sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
+            constexpr int s = decltype(sc)::value;
+            if (!(NN > 0 && s < nsub) || s != A.solve_sub) return;
+            if (S::NSUB > 1) enter_sub(sc);
+            set_p(lp);
+            double jp[NPr], dz;
+            int phase = 0;
+            bool relearn = false, mine = false;
+            for (;;) {
+                phase = wv::opaque(phase);
+                (void)evaluate(lz);
+                if (phase == 1) {
+                    (void)LU::pivot_order(a, orig, lig, grp);
+                    orig = relearn ? orig : lig;
+                    adopt();
+                    phase = 2;
+                    continue;
+                }
+                calc_jp(jp);
+                dz = res;
+                const unsigned long long viol = LU::template solve_inplace<NP, false, OS, false, true>(a, dz, jp, ojp, false);
+                mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
+                if (viol != 0ull && phase == 0) {
+                    relearn = mine;
+                    phase = 1;
+                    continue;
+                }
+                break;
+            }
+            if (valid && lig < A.nn_io)     // column-major nn x np per instance; NaN if J is singular there
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    if (j < A.np_io) A.jac_out[(inst * A.np_io + j) * A.nn_io + lig] = mine ? (double)NAN : -jp[j];
+                });
+        });
+        return;
+    }
+
     // ---- report words -------------------------------------------------------------------
     // kept in LDS (one copy per instance, updated by the instance's lane 0 once per sample)
     // rather than in registers of all 16 lanes: they are never needed inside the solver loop

@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
-    "acme_batch_solve", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
+    "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
 
@@ -110,6 +110,7 @@ class Library:
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
+        L.acme_batch_get_extrapolation_jacobian.argtypes = [vp, C.c_int, dp, C.c_int, vp]
         L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.acme_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
         L.acme_batch_get_report.argtypes = [vp, C.POINTER(Report)]
@@ -387,6 +388,14 @@ class ModelRunner:
         self.lib.check(self.lib.L.acme_batch_solve(self.h, int(sub), _dp(p), _dp(z), _ip(conv), _ip(iters),
                                                    ACME_MEM_HOST, None))
         return z, conv.astype(bool), iters
+
+    def get_extrapolation_jacobian(self, sub=0):
+        """Batched ``get_extrapolation_jacobian(model.solvers[sub+1])`` (src/solvers.jl:198-201):
+        (N, nn, np) array of dz/dp = -(J \\ Jp) at every instance's extrapolation origin."""
+        s = self.model.subs[sub]
+        jac = np.zeros((self.n, s.np, s.nn))          # ABI layout: per instance column-major nn x np
+        self.lib.check(self.lib.L.acme_batch_get_extrapolation_jacobian(self.h, int(sub), _dp(jac), ACME_MEM_HOST, None))
+        return np.ascontiguousarray(jac.transpose(0, 2, 1))
 
     def get_state(self):
         """(x, last_p, last_z): model.x and the extrapolation origin of every instance."""

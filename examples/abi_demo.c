@@ -74,6 +74,14 @@ int main(void) {
     int bad = 0;
     for (int k = 0; k < 4; ++k) bad |= fabs(y1[k] - head[k]) > 5e-6 * fmax(1e-1, fabs(head[k]));
     for (int k = 0; k < 3; ++k) bad |= fabs(y1[T - 3 + k] - tail[k]) > 5e-6;
+    /* the solver plugin surface: get_extrapolation_jacobian = dz/dp at each instance's origin
+     * (nn x np = 2 x 1 here), finite for every instance after a converged run */
+    double jac[N * 2 * 1];
+    CHECK(acme_batch_get_extrapolation_jacobian(bt, 0, jac, ACME_MEM_HOST, NULL));
+    for (int i = 0; i < N; ++i) {
+        printf("amplitude %5.1f V: dz/dp at the origin = [%.6g, %.6g]\n", amp[i], jac[2 * i], jac[2 * i + 1]);
+        if (!(jac[2 * i] == jac[2 * i]) || !(jac[2 * i + 1] == jac[2 * i + 1])) return 4;
+    }
     float ms = 0.f;
     CHECK(acme_batch_last_kernel_ms(bt, &ms));
     printf("doctest vector %s; last kernel %.3f ms\n", bad ? "MISMATCH" : "reproduced", ms);

@@ -24,6 +24,8 @@
  *   * Every entry point returns ACME_OK (0) or a negative error code and never unwinds;
  *     acme_last_error() returns a thread-local message for the last failure.
  *   * Threading: handles are single-owner; distinct handles are independent.
+ *   * Devices: a batch lives on one HIP device (acme_options.device); every entry point switches
+ *     to it for the duration of the call and restores the caller's current device on return.
  *   * Failure semantics of step! (src/ACME.jl:688-694) are reported per instance in
  *     acme_report: n_warn counts "Failed to converge" warnings; first_nonfinite >= 0 is
  *     the sample at which the reference would have thrown -- that instance stops
@@ -148,6 +150,15 @@ int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int m
  * touched and nothing is added to the run reports.  mem/stream as for acme_batch_run. */
 int acme_batch_solve(acme_batch *b, int sub, const double *p, double *z, int *converged,
                      int *iters, int mem, void *stream);
+
+/* get_extrapolation_jacobian(solver) (src/solvers.jl:198-201; what linearize builds the small-signal
+ * model from, :407-414) for every instance: jac is [N][np_sub][nn_sub], i.e. per instance the
+ * nn x np matrix  -(J \ Jp)  = dz/dp at the instance's extrapolation origin (last_p, last_z) of
+ * sub-problem `sub`, column-major like Julia's Matrix{Float64}; NaN where J is singular there.  The
+ * origin is re-linearised on the device (set_extrapolation_origin, :183-196, with the columns of Jp
+ * riding along in the elimination); the batch's state is not modified.  mem/stream as for
+ * acme_batch_run. */
+int acme_batch_get_extrapolation_jacobian(acme_batch *b, int sub, double *jac, int mem, void *stream);
 
 /* milliseconds the last acme_batch_run kernel took on the device (HIP events recorded on
  * the launch stream); synchronises with that launch */

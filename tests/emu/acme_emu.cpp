@@ -114,9 +114,10 @@ void run_block(int bid, void (*entry)(void *), void *arg) {
 // ------------------------------------------------------------------------------------------
 struct KernelEntry {
     Dims d;
-    const void *fn;
+    const void *fn, *fn_jac;
     int lds_shared, lds_per_inst, state;
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
+    int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
 };
 
 struct LaunchCtx {
@@ -129,13 +130,18 @@ template <class S> static void fiber_entry(void *p) {
     wave_main<S>(*c->A, c->lds);
 }
 
-template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
+template <class S> static void fiber_entry_jac(void *p) {
+    LaunchCtx *c = (LaunchCtx *)p;
+    if constexpr (S::NN > 0) wave_main<S, MODE_JAC>(*c->A, c->lds);
+}
+
+template <class S, bool JAC> static int launch_any(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
     std::vector<double> lds(lds_bytes / sizeof(double) + 64);
     LaunchCtx c{&A, lds.data()};
     for (unsigned b = 0; b < grid; ++b) {
         // poison the LDS with NaNs: a kernel reading uninitialised LDS into a result shows up
         for (auto &v : lds) v = std::nan("");
-        emu::run_block((int)b, &fiber_entry<S>, &c);
+        emu::run_block((int)b, JAC ? &fiber_entry_jac<S> : &fiber_entry<S>, &c);
     }
     return 0;
 }
@@ -143,9 +149,10 @@ template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
 #define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false), \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false), \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
-                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
+                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, false>,                                   \
+                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, true>},
         ACME_EMU_SHAPES(ACME_X)
 #undef ACME_X
     };

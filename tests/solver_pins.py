@@ -144,3 +144,37 @@ def check_parabola(lib):
     for i in range(len(p)):
         zr, cr, _ = RefRunner(ms).solve(p[i])
         assert cr == convs[i]
+
+
+def check_extrapolation_jacobian(lib):
+    """acme_batch_get_extrapolation_jacobian = get_extrapolation_jacobian(solver) (src/solvers.jl:
+    198-201) = -(J \\ Jp) at each instance's extrapolation origin: against a host evaluation of the
+    element table at the same (p, z), for the big (recorded-elimination) and the small (J^-1 Jp)
+    origin representations, after solves that moved the origins to different points."""
+    from helpers import load
+    from acme_jl_amd.hostsolve import eval_table
+    from test_gpu_parity import trajectory_ps
+    from helpers import sweep_inputs
+    for name in ("superover_var", "superover_fixed", "birdie_var", "diodeclipper"):
+        m = load(name)
+        s = m.subs[0]
+        ps = trajectory_ps(m, sweep_inputs(name, 2, 300)[1], every=23)
+        N = len(ps)
+        r = _runner(lib, m, N)
+        # fresh batch: origin = (0, init_z)
+        jac0 = r.get_extrapolation_jacobian()
+        z, conv, _ = r.solve(ps)
+        assert conv.all()
+        jac = r.get_extrapolation_jacobian()
+        _, lp, lz = r.get_state()
+        np.testing.assert_allclose(lp, ps, rtol=0, atol=0)
+        for i in range(N):
+            for (p_, z_, got) in ((np.zeros(s.np), s.init_z, jac0[i]), (lp[i], lz[i], jac[i])):
+                q = s.q0 + s.pexp @ p_ + s.fq @ z_
+                _, jq = eval_table(s.table, q.tolist(), s.nn, s.nq)
+                jq = np.asarray(jq)
+                ref = -np.linalg.solve(jq @ s.fq, jq @ s.pexp)
+                np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+        # the export does not disturb the batch: the same solve again gives the same answer bit for bit
+        z2, _, _ = _runner(lib, m, N).solve(ps)
+        assert np.array_equal(z, z2)

@@ -14,3 +14,7 @@ def test_emulated_pivot_sweep(emu_lib):
 
 def test_emulated_parabola(emu_lib):
     solver_pins.check_parabola(emu_lib)
+
+
+def test_emulated_extrapolation_jacobian(emu_lib):
+    solver_pins.check_extrapolation_jacobian(emu_lib)

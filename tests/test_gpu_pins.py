@@ -20,3 +20,7 @@ def test_pivot_sweep(hip_lib):
 
 def test_parabola_homotopy(hip_lib):
     solver_pins.check_parabola(hip_lib)
+
+
+def test_extrapolation_jacobian(hip_lib):
+    solver_pins.check_extrapolation_jacobian(hip_lib)
