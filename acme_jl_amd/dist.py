@@ -77,6 +77,26 @@ def gather_outputs(y_local, counts, dst=0):
     return torch.cat(parts, dim=0) if rank == dst else None
 
 
+def collect_outputs(y_local, mode="rank0", dst=0):
+    """Collection of equally sized output shards [n, T, ny]: ``rank0`` -- every rank's shard to ``dst``
+    (returns the [world*n, T, ny] tensor there, None elsewhere); ``allgather`` -- to every rank (one
+    RCCL all-gather into a preallocated tensor).  With the gloo backend (CPU tests, one-device
+    rehearsal) the shards travel as host tensors."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and y_local.is_cuda:
+        y_local = y_local.cpu()
+    if mode == "allgather":
+        out = torch.empty((world * y_local.shape[0],) + tuple(y_local.shape[1:]), dtype=y_local.dtype,
+                          device=y_local.device)
+        dist.all_gather_into_tensor(out, y_local.contiguous())
+        return out
+    if mode == "rank0":
+        return gather_outputs(y_local, [y_local.shape[0]] * world, dst=dst)
+    raise ValueError(mode)
+
+
 def reduce_reports(report_arrays, device=None):
     """All-reduce the solver counters of every rank: returns dict of global totals."""
     import torch

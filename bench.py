@@ -149,19 +149,43 @@ def algorithmic_flops(model, iters_per_sample):
 
 
 def _cpu_worker(args):
-    fixture, rows, T, solver = args
+    """Times the oracle on `rows` (one fresh runner per stream): the first pass over the signal (cold
+    solver state, empty solution cache) and, if `warm`, a second pass continuing it -- the regime the
+    GPU's timed steps are in (bench.py warms the GPU runner up with the same signal first)."""
+    fixture, rows, T, solver, warm, reflib = args
+    if reflib:
+        os.environ["ACME_REF_LIB"] = reflib
     from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
     from oracle.refpy import RefRunner
     m = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
-    t0 = time.perf_counter()
-    iters = 0
+    cold = warm_t = 0.0
+    iters = iters_warm = 0
     for u in rows:
         r = RefRunner(m)
         if solver == CachingHomotopySolver:
             r.set_cache_limit(16)      # the GPU's bounded store: same algorithm on both sides
+        t0 = time.perf_counter()
         r.run(u)
+        cold += time.perf_counter() - t0
         iters += r.report.iters_total
-    return time.perf_counter() - t0, iters
+        if warm:
+            t0 = time.perf_counter()
+            r.run(u)
+            warm_t += time.perf_counter() - t0
+            iters_warm += r.report.iters_total
+    return cold, iters, warm_t, iters_warm
+
+
+def build_native_oracle():
+    """-O3 -march=native build of oracle/acme_ref.c for THIS host (never shipped: not portable)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"libacme_ref_native_{os.getpid()}.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", f"NATIVE_OUT={out}"])
+        return out
+    except (OSError, subprocess.CalledProcessError):
+        return None
 
 
 def host_cores():
@@ -190,30 +214,53 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     n = len(pots) if pots is not None else (1 if np.isscalar(amp) else len(amp))   # scalar: identical streams
     pick = np.linspace(0, n - 1, cores * per_core).astype(int)
     sig = np.sin(2 * np.pi * 1000.0 / fs * np.arange(T_cpu))
-    jobs = []
-    for w in range(cores):
-        rows = []
-        for i in pick[w::cores]:
-            u = np.zeros((model.nu, T_cpu))
-            u[0] = (amp if np.isscalar(amp) else amp[i]) * sig
-            if pots is not None:
-                u[1:] = pots[i][:, None]
-            rows.append(u)
-        jobs.append((fixture, rows, T_cpu, model.solver))
+
+    def jobs(warm, reflib, stride=1):
+        out = []
+        for w in range(cores):
+            rows = []
+            for i in pick[w::cores][::stride]:
+                u = np.zeros((model.nu, T_cpu))
+                u[0] = (amp if np.isscalar(amp) else amp[i]) * sig
+                if pots is not None:
+                    u[1:] = pots[i][:, None]
+                rows.append(u)
+            out.append((fixture, rows, T_cpu, model.solver, warm, reflib))
+        return out
     with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs, chunksize=1)
+        # leg 1 (the headline CPU figure, as in round 1): -O2 build, cold streams; its second pass
+        # over the same signal gives the warm-state figure
+        res = pool.map(_cpu_worker, jobs(True, None), chunksize=1)
+        # leg 2: the same source built -O3 -march=native on this host, on a third of the streams
+        native = build_native_oracle()
+        res_n = pool.map(_cpu_worker, jobs(True, native, stride=3), chunksize=1) if native else None
+    if native:
+        try:
+            os.remove(native)
+        except OSError:
+            pass
     slowest = max(r[0] for r in res)
     units = len(pick) * T_cpu
-    return {
+    out = {
         "value": units / slowest, "unit": "circuit-instance*samples/sec", "cores": cores,
         "kind": "port",
         "sample": (f"{len(pick)} instances spread over the sweep" if n > 1 else
                    f"{len(pick)} streams of the nominal-component model (the Monte-Carlo instances differ in "
                    "component values, not in cost)") + f" x {T_cpu} samples, {per_core} oracle "
                   f"streams on each of {cores} cores, slowest worker {slowest:.1f} s "
-                  "(C restatement oracle/acme_ref.c, gcc -O2, scalar)",
+                  "(C restatement oracle/acme_ref.c, gcc -O2, scalar; fresh solver state, as `value` of round 1)",
         "iters_per_sample": sum(r[1] for r in res) / units,
+        # the same streams continued over a second pass of the signal: warm solver state and solution
+        # caches, the regime of the GPU's timed steps
+        "warm_value": units / max(r[2] for r in res),
+        "warm_iters_per_sample": sum(r[3] for r in res) / units,
     }
+    if res_n:
+        units_n = sum(len(j[1]) for j in jobs(False, None, stride=3)) * T_cpu
+        out["native_value"] = units_n / max(r[0] for r in res_n)
+        out["native_warm_value"] = units_n / max(r[2] for r in res_n)
+        out["native_note"] = "gcc -O3 -march=native build of the same C source on this host, a third of the streams"
+    return out
 
 
 def main():
@@ -231,6 +278,10 @@ def main():
     ap.add_argument("--solver", default=None, choices=["caching", "homotopy", "simple"],
                     help="caching = HomotopySolver{CachingSolver{SimpleSolver}}, the reference's default stack "
                          "(GPU: bounded 16-entry store per instance); homotopy = HomotopySolver{SimpleSolver}")
+    ap.add_argument("--gather", default=None, choices=["none", "rank0", "allgather"],
+                    help="collection of the sharded outputs after the timed steps, timed separately (gather_ms): "
+                         "rank0 = every rank sends its y to rank 0 (grouped send/recv), allgather = RCCL all-gather; "
+                         "default: rank0 when N > 1, none at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=None)
     args = ap.parse_args()
@@ -300,8 +351,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    cold_ms = None
+    for w in range(args.warmup):
+        if w == 0:      # the first step of a fresh batch: cold solver state, empty solution caches
+            sync()
+            tc = time.perf_counter()
         runner.run_torch(u, y)
+        if w == 0:
+            sync()
+            cold_ms = 1e3 * (time.perf_counter() - tc)
     sync()
     runner.reset_report()
     runner.kernel_time(reset=True)
@@ -331,12 +389,34 @@ def main():
         iters_total, n_warn, n_dead, iters_max = (float(stats[1]), float(stats[2]), float(stats[3]),
                                                   float(stats[4]))
     checksum = float(torch.nan_to_num(y).abs().sum())
-    if os.environ.get("ACME_BENCH_FORCE_DIST") == "1":
-        # test-only (never set by the driver): the optional output collection of SURVEY 8(e) over the
-        # same backend, on a small slice, outside the timed region
-        from acme_jl_amd.dist import gather_outputs
-        part = gather_outputs(y[:4].contiguous(), [4] * world, dst=0)
-        assert rank != 0 or (tuple(part.shape) == (4 * world, T, model.ny) and torch.equal(part[:4], y[:4]))
+    checksums = [checksum]
+    if use_dist:       # every rank's output checksum (shards must differ: other grid cells / other seeds)
+        cs = [None] * world
+        dist.all_gather_object(cs, checksum)
+        checksums = [float(c) for c in cs]
+    # Collection of the sharded outputs (SURVEY 8e / north star: "gather of outputs over xGMI"): the
+    # last step's y of every rank, timed on its own between barriers.  It is not part of `value`
+    # (instances never interact: no collective sits on the data path); `value_incl_gather` charges
+    # one such collection to every step.
+    gather_mode = args.gather or ("rank0" if use_dist and world > 1 else "none")
+    if os.environ.get("ACME_BENCH_FORCE_DIST") == "1" and args.gather is None:
+        gather_mode = "rank0"          # single-rank rehearsal of the collective path (tests)
+    gather_ms = gathered_shape = None
+    if gather_mode != "none" and use_dist:
+        from acme_jl_amd.dist import collect_outputs
+        sync()
+        tg = time.perf_counter()
+        full = collect_outputs(y, mode=gather_mode, dst=0)
+        sync()
+        gather_ms = 1e3 * (time.perf_counter() - tg)
+        gm = torch.tensor([gather_ms], dtype=torch.float64, device=dev if not rehearsal else "cpu")
+        dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+        gather_ms = float(gm[0])
+        if full is not None:
+            gathered_shape = list(full.shape)
+            assert gathered_shape == [world * n_per_gpu, T, model.ny]
+            assert torch.equal(full[rank * n_per_gpu:(rank + 1) * n_per_gpu].to(y.device), y)
+        del full
 
     if rank == 0:
         units = world * n_per_gpu * T * args.steps
@@ -374,8 +454,16 @@ def main():
                                "solutions per instance (reference: unbounded k-d tree), same lookup/store rules; "
                                "--solver homotopy runs HomotopySolver{SimpleSolver}",
                 "parallelism": f"instance-sharded x{world}",
+                "rccl_ranks": world if (use_dist and not rehearsal) else 0,
+                "collective_backend": ("gloo (one-device rehearsal)" if rehearsal else "nccl (RCCL)") if use_dist else None,
+                "gather": gather_mode, "gather_ms": gather_ms, "gathered_shape": gathered_shape,
+                "value_incl_gather": (units / (elapsed + args.steps * gather_ms * 1e-3)) if gather_ms is not None else None,
+                "cold_first_step_ms": cold_ms,
+                "timed_steps_note": "the timed steps continue the signal of the warm-up steps: warm solver state and "
+                                    "solution caches (steady state); cold_first_step_ms is the first step of the fresh batch",
                 "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,
                 "n_warn": n_warn, "n_nonfinite_instances": n_dead, "y_abs_sum_rank0": checksum,
+                "y_abs_sum_per_rank": checksums,
                 **({"host_setup": setup} if setup else {}),
             },
             "roofline": {

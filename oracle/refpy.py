@@ -33,7 +33,9 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libacme_ref.so")
+        # ACME_REF_LIB: file name of the build to load (bench.py times libacme_ref_native.so, the
+        # -O3 -march=native build of the same source, as a second CPU leg)
+        path = os.path.join(_HERE, os.environ.get("ACME_REF_LIB", "libacme_ref.so"))
         src = os.path.join(_HERE, "acme_ref.c")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()

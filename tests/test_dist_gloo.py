@@ -33,6 +33,13 @@ def _worker(rank, world, port, out):
     rep = dict(n_warn=np.array([rank + 1]), first_nonfinite=np.array([-1 if rank else 3]),
                iters_total=np.array([10 * (rank + 1)]), iters_max=np.array([7 + rank]))
     tot = reduce_reports(rep)
+    # equally sized shards through both collection modes of bench.py --gather
+    from acme_jl_amd.dist import collect_outputs
+    shard = torch.full((3, 5, 2), float(rank + 1), dtype=torch.float64)
+    g0 = collect_outputs(shard, mode="rank0", dst=0)
+    ga = collect_outputs(shard, mode="allgather")
+    expect = torch.cat([torch.full((3, 5, 2), float(r + 1), dtype=torch.float64) for r in range(world)])
+    same = same and torch.equal(ga, expect) and ((g0 is None) if rank else torch.equal(g0, expect))
     if rank == 0:
         ok = same and y.shape == (n_total, 4, 1) and torch.equal(y[:, 0, 0], torch.arange(n_total, dtype=torch.float64))
         ok = ok and tot == dict(n_warn=3, n_nonfinite=1, iters_total=30, iters_max=8)

@@ -433,6 +433,48 @@ def test_bench_multirank_path_over_rccl(hip_lib):
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 1e6
     assert rec["config"]["n_warn"] == 0 and rec["config"]["n_nonfinite_instances"] == 0
+    # RCCL really ran (one rank) and the output collection was timed
+    assert rec["config"]["rccl_ranks"] == 1 and rec["config"]["gather_ms"] is not None
+    assert rec["config"]["gathered_shape"] == [256, 2000, 1]
+
+
+def _rehearsal(workload, extra, world=8, timeout=420):
+    """bench.py under torch.distributed.run with `world` ranks sharing the one GPU of the test box
+    (ACME_BENCH_ONE_DEVICE=1: gloo instead of RCCL, every rank on cuda:0): the whole multi-rank code
+    path -- model broadcast, per-rank shards, counters, output collection -- short of RCCL itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACME_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--steps", "1", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_eight_rank_rehearsal_configs_4_and_5(hip_lib):
+    """BASELINE configs 4 and 5 are 8-GPU runs (8192 / 2048 instances per GPU).  The test box has one
+    GPU: 8 ranks share it and run reduced shards through the same code path as the driver's
+    `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` -- per-rank Monte-Carlo seeds and
+    grid slices (every shard's checksum differs), counters reduced over the ranks, outputs collected
+    on rank 0 and by all-gather with the shapes the full run would have."""
+    rec = _rehearsal("superover_montecarlo", ["--instances", "64", "--samples", "1500", "--gather", "rank0"])
+    assert rec["n_gpus"] == 8 and rec["config"]["instances_per_gpu"] == 64
+    assert rec["config"]["gathered_shape"] == [8 * 64, 1500, 1] and rec["config"]["gather_ms"] > 0
+    assert rec["config"]["rccl_ranks"] == 0 and "gloo" in rec["config"]["collective_backend"]
+    assert rec["config"]["n_warn"] == 0 and rec["config"]["n_nonfinite_instances"] == 0
+    cs = rec["config"]["y_abs_sum_per_rank"]
+    assert len(cs) == 8 and len({round(c, 6) for c in cs}) == 8      # 8 different seeds -> 8 different shards
+    assert 2.0 < rec["config"]["newton_iters_per_sample"] < 12.0
+    rec = _rehearsal("birdie_grid", ["--instances", "128", "--samples", "3000", "--gather", "allgather"])
+    assert rec["n_gpus"] == 8 and rec["config"]["gathered_shape"] == [8 * 128, 3000, 1]
+    assert rec["config"]["n_warn"] == 0 and rec["config"]["solver"] == "HomotopySolver{SimpleSolver}"
+    cs = rec["config"]["y_abs_sum_per_rank"]
+    assert len({round(c, 6) for c in cs}) == 8 and cs == sorted(cs)     # amplitude grows with the rank
+    assert rec["value"] > 1e6 and rec["config"]["value_incl_gather"] < rec["value"]
 
 
 def test_empty_and_single_sample_runs(hip_lib):
