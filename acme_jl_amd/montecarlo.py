@@ -163,12 +163,31 @@ class _BatchHomotopy:
         return z, conv
 
 
-def _initial_solution_batch(table, fq, q0, nn):
+def _initial_solution_batch(table, fq, q0, nn, device=None):
     """initial_solution (src/ACME.jl:453-464) for N instances: homotopy on q from 0 to q0_i with z
     starting at 0, each instance following the reference's iteration (the result is only defined
-    up to the solver tolerance, so the path matters for parity).  fq: [N, nq, nn], q0: [N, nq]."""
+    up to the solver tolerance, so the path matters for parity).  fq: [N, nq, nn], q0: [N, nq].
+
+    ``device``: None -> the numpy restatement above (no GPU needed); else a dict(lib=..., device=...)
+    -> all N solves in one batched ``acme_batch_solve`` on the GPU (``analysis.solve_rays``: the
+    same homotopy path, walked by the same kernel that later runs the models).
+    Shapes whose per-instance blocks do not fit the LDS fall back to numpy."""
     if nn == 0:
         return np.zeros((q0.shape[0], 0))
+    if device is not None:
+        from .analysis import solve_rays
+        from .runner import AcmeError
+        try:
+            z, conv = solve_rays(table, None, nn, q0.shape[1], q0, fq, lib=device.get("lib"), device=device.get("device"))
+        except AcmeError as e:
+            if "LDS" not in str(e):
+                raise
+            device.setdefault("fallbacks", []).append(str(e))
+        else:
+            if not conv.all():
+                raise RuntimeError("Failed to find initial solution")
+            device["solved"] = device.get("solved", 0) + q0.shape[0]
+            return z
     z, conv = _BatchHomotopy(table, fq, nn).solve(q0)
     if not conv.all():
         raise RuntimeError("Failed to find initial solution")
@@ -222,11 +241,18 @@ class BatchModels:
         return (self.model(i) for i in range(self.n))
 
 
-def derive_batch(make_circuit, t, component_values, solver=HomotopySolver, decompose_nonlinearity=True):
+def derive_batch(make_circuit, t, component_values, solver=HomotopySolver, decompose_nonlinearity=True,
+                 init_on_device=None):
     """``make_circuit(value)`` builds the circuit, calling ``value(name, nominal)`` for every
     component that carries a tolerance (e.g. ``examples.superover(..., value=value)``).
     ``component_values``: dict name -> array[N] of that component's value in each instance
-    (components not listed stay nominal).  Returns ``BatchModels``."""
+    (components not listed stay nominal).  Returns ``BatchModels``.
+
+    ``init_on_device``: None -> the construction-time solves (``initial_solution`` and the folded
+    constant sub-problems) run as a numpy batch on the host; ``True`` or ``dict(lib=..., device=...)``
+    -> they run on the GPU, all instances in one batched solve per sub-problem (the dict comes back
+    with ``solved`` = number of equations solved there)."""
+    dev = None if init_on_device is None else (init_on_device if isinstance(init_on_device, dict) else {})
     names = list(component_values)
     n = len(next(iter(component_values.values()))) if names else 1
     cols = {k: np.asarray(v, dtype=np.float64) for k, v in component_values.items()}
@@ -271,7 +297,7 @@ def derive_batch(make_circuit, t, component_values, solver=HomotopySolver, decom
             fqprev = _arr(mats["fqprev_fulls"][idx], nb, (nq, zall.shape[1]))
             q = _arr(mats["q0s"][idx], nb, (nq,)) + np.einsum("nqj,nj->nq", fqprev, zall)
             fq = _arr(mats["fqs"][idx], nb, (nq, model_nns[idx]))
-            zs[idx] = _initial_solution_batch(tables[idx], fq, q, model_nns[idx])
+            zs[idx] = _initial_solution_batch(tables[idx], fq, q, model_nns[idx], device=dev)
         return zs
 
     init_zs = init_all()

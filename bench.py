@@ -67,7 +67,7 @@ def grid_inputs(workload, rank, world, n_per_gpu, T):
     raise ValueError(workload)
 
 
-def montecarlo_models(rank, n_per_gpu):
+def montecarlo_models(rank, n_per_gpu, init_on_device=None):
     """BASELINE config 4: fixed-pot superover (1.0, 1.0, 1.0), every resistor, capacitor and pot
     track scaled by 1 + 0.05*U(-1,1), semiconductors nominal.  Every rank derives its own shard
     locally from (seed 20250905, rank) with the structure-replaying front end."""
@@ -79,7 +79,7 @@ def montecarlo_models(rank, n_per_gpu):
     make(lambda name, v: nominal.setdefault(name, v))
     rng = np.random.Generator(np.random.PCG64([20250905, rank]))
     vals = {k: v * (1 + 0.05 * rng.uniform(-1, 1, n_per_gpu)) for k, v in nominal.items()}
-    return derive_batch(make, Fraction(1, 44100), vals)
+    return derive_batch(make, Fraction(1, 44100), vals, init_on_device=init_on_device)
 
 
 def make_u(torch, dev, model, pots, amp, n, T, fs=FS):
@@ -334,8 +334,10 @@ def main():
     setup = {}
     if args.workload == "superover_montecarlo":
         t0 = time.perf_counter()
-        batch = montecarlo_models(rank, n_per_gpu)
+        init_info = {"device": local_rank}       # initial_solution of every instance: one batched GPU solve
+        batch = montecarlo_models(rank, n_per_gpu, init_on_device=init_info)
         setup["derive_s"] = time.perf_counter() - t0
+        setup["initial_solutions_on_gpu"] = init_info.get("solved", 0)
         t0 = time.perf_counter()
         batch.solver = solver
         model = batch.model(0)

@@ -111,3 +111,26 @@ def opamp_shelving_circuit(Amax, GBP):
         ("c", capacitor(22e-9), {1: ("r2", 2), 2: "gnd"}),
         ("output", voltageprobe(), {"+": ("op", "out+"), "-": "gnd"}),
     ])
+
+
+def two_stage_clipper(bias=0.0):
+    """Two diode-clipper stages separated by an ideal op-amp buffer: the nonlinearity decomposes into
+    two sub-problems (one per stage), the second fed by the first through the buffer -- a small model
+    with nsub = 2 and a regular (I - a), for steadystate / linearize on decomposed models.  ``bias``:
+    a DC source in series with the input, so that the steady state is not the origin."""
+    from acme_jl_amd.circuit import capacitor, diode, opamp, resistor, voltageprobe, voltagesource
+    from acme_jl_amd.examples import build
+    return build([
+        ("j_in", voltagesource(), {"-": "gnd"}),
+        ("j_b", voltagesource(bias), {"-": ("j_in", "+")}),
+        ("r1", resistor(1e3), {1: ("j_b", "+")}),
+        ("c1", capacitor(47e-9), {1: ("r1", 2), 2: "gnd"}),
+        ("d1", diode(is_=1e-15), {"-": "gnd", "+": ("r1", 2)}),
+        ("d2", diode(is_=1.8e-15), {"-": ("r1", 2), "+": "gnd"}),
+        ("buf", opamp(), {"in+": ("r1", 2), "in-": "bo", "out+": "bo", "out-": "gnd"}),
+        ("r2", resistor(2.2e3), {1: "bo"}),
+        ("c2", capacitor(22e-9), {1: ("r2", 2), 2: "gnd"}),
+        ("d3", diode(is_=4e-9, eta=2), {"-": "gnd", "+": ("r2", 2)}),
+        ("d4", diode(is_=3e-9, eta=2), {"-": ("r2", 2), "+": "gnd"}),
+        ("j_out", voltageprobe(), {"-": "gnd", "+": ("r2", 2)}),
+    ])

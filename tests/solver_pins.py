@@ -178,3 +178,47 @@ def check_extrapolation_jacobian(lib):
         # the export does not disturb the batch: the same solve again gives the same answer bit for bit
         z2, _, _ = _runner(lib, m, N).solve(ps)
         assert np.array_equal(z, z2)
+
+
+def check_decomposed_analysis(lib):
+    """steadystate / linearize on a model with several nonlinear sub-problems (src/ACME.jl:474-550):
+    the decomposed two-stage clipper (nsub = 2, the second stage fed by the first through fqprev)
+    against the non-decomposed derivation of the same circuit -- steady state equal to rounding and a
+    fixed point of the oracle's run!, linear models equal to rounding and tracking the nonlinear model
+    around the operating point; checksteady! of test/runtests.jl:664-671 on the decomposed model."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.analysis import linearize, steadystate, steadystate_
+    from acme_jl_amd.model import DiscreteModel
+    from oracle.refpy import RefRunner
+    t = Fraction(1, 44100)
+    m = DiscreteModel(circuits.two_stage_clipper(0.6), t)
+    m1 = DiscreteModel(circuits.two_stage_clipper(0.6), t, decompose_nonlinearity=False)
+    assert len(m.subs) == 2 and len(m1.subs) == 1 and np.abs(m.subs[1].fqprev).max() > 0
+    xs, xs1 = steadystate(m, lib=lib), steadystate(m1, lib=lib)
+    np.testing.assert_allclose(xs, xs1, rtol=1e-9, atol=1e-18)
+    # N operating points at once
+    U = np.linspace(-0.3, 0.4, 5)[:, None]
+    X = steadystate(m, U, lib=lib)
+    for i in range(5):
+        np.testing.assert_allclose(X[i], steadystate(m1, U[i], lib=lib), rtol=1e-8, atol=1e-16)
+    # checksteady!: one sample from the steady state leaves the state where it is
+    r = _runner(lib, m, 2)
+    steadystate_(r)
+    r.set_resabstol(1e-13)
+    r.run(np.zeros((2, m.nu, 1)))
+    np.testing.assert_allclose(r.get_state()[0], np.tile(xs, (2, 1)), rtol=1.5e-8, atol=1e-14)
+    lin, lin1 = linearize(m, lib=lib), linearize(m1, lib=lib)
+    for k in ("a", "b", "x0", "dy", "ey", "y0"):
+        np.testing.assert_allclose(getattr(lin, k), getattr(lin1, k), rtol=1e-6, atol=1e-9)
+    u = 1e-5 * np.sin(2 * np.pi * 1000 / 44100 * np.arange(300))[None]
+    ref = RefRunner(m)
+    ref.set_resabstol(1e-14)
+    ref.x = xs
+    y = ref.run(u)
+    rl = _runner(lib, lin, 1)
+    steadystate_(rl)
+    assert np.abs(rl.run(u) - y).max() < 5e-9          # second-order small at 10 uV
+    # the reference's literal constant-term formula does not reproduce the operating point
+    bad = linearize(m, lib=lib, reference_offsets=True)
+    assert np.abs(bad.y0 - lin1.y0).max() > 1e-3
