@@ -101,6 +101,34 @@ ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int
     return L;
 }
 
+// Constant block of the lane-per-instance kernel (acme_lane_kernel.h): the same numbers as the model
+// image, regrouped so that everything one residual row (or one row of the linear update) needs is
+// CONTIGUOUS -- the kernel reads it with wave-uniform addresses, i.e. wide scalar loads.
+//   residual row r at r * row:  q0r[3] | pexpr[3][np] | fqr[3][nn] | unified row constants UR_SA..UR_W1 | kind
+//   p row i at p0 + i * pstr:   dq[i][0..nx) | eq[i][0..nu)
+//   y row i at y0 + i * xstr:   y0[i] | dy[i][0..nx) | ey[i][0..nu) | fy[i][0..nn)
+//   x row i at x0 + i * xstr:   x0[i] | a[i][0..nx)  | b[i][0..nu)  | c[i][0..nn)
+struct LaneLayout {
+    int row, q0, pexp, fq, ur, kind;    // row stride and offsets inside a residual row
+    int p0, pstr, y0, x0, xstr, total;
+};
+ACME_HD constexpr LaneLayout make_lane_layout(int nn, int np, int nx, int nu, int ny) {
+    LaneLayout l{};
+    l.q0 = 0;
+    l.pexp = 3;
+    l.fq = 3 + 3 * np;
+    l.ur = l.fq + 3 * nn;
+    l.kind = l.ur + (UR_W1 - UR_SA + 1);
+    l.row = (l.kind + 1 + 7) & ~7;
+    l.pstr = (nx + nu + 1) & ~1;
+    l.xstr = (1 + nx + nu + nn + 1) & ~1;
+    l.p0 = nn * l.row;
+    l.y0 = l.p0 + np * l.pstr;
+    l.x0 = l.y0 + ny * l.xstr;
+    l.total = ((l.x0 + nx * l.xstr) + 7) & ~7;
+    return l;
+}
+
 // per-instance report (int64 words), mirrors the reference's failure semantics
 // (src/ACME.jl:688-694)
 enum ReportWord { RW_NWARN = 0, RW_FIRST_NONCONV = 1, RW_FIRST_NONFINITE = 2, RW_ITERS_TOTAL = 3,
@@ -111,6 +139,7 @@ struct KArgs {
     long long image_stride;  // 0: one shared image; else doubles between per-instance images
     const double *rowc;      // ROWC x 16 row constants (const index major)
     const int *rowi;         // ROWI x 16 row ints
+    const double *lanec;     // constant block of the lane-per-instance kernel (LaneLayout), or nullptr
     const double *u;         // [n_inst][T][nu_io]
     double *y;               // [n_inst][T][ny_io]
     double *state;           // [n_inst][nx + np + nn] : x | last_p | last_z

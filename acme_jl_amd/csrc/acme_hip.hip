@@ -15,6 +15,7 @@
 #include "../../include/acme_hip.h"
 #include "acme_wave_hip.h"
 #include "acme_kernel.h"
+#include "acme_lane_kernel.h"
 #include "acme_pack.h"
 
 using namespace acme;
@@ -35,13 +36,23 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_jac_kernel(KArgs
     wave_main<S, MODE_JAC>(A, acme_lds);
 }
 
+// run! for small models, one lane per instance (acme_lane_kernel.h): one wave per SIMD is all these
+// batches offer, so the kernel is built for the shortest dependent chain per sample, not for occupancy
+template <class S>
+__global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    lane_main<S>(A, acme_lds);
+}
+
 struct KernelEntry {
     Dims d;
-    const void *fn, *fn_jac;
+    const void *fn, *fn_jac, *fn_lane;
     int lds_shared, lds_per_inst;  // doubles
     int state;                     // doubles of state per instance
+    int lds_lane_plain, lds_lane_caching;   // doubles, lane kernel (0: shape not supported by it)
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
+    int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
 };
 
 template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
@@ -62,15 +73,36 @@ template <class S> static const void *jac_fn() {
     else return nullptr;
 }
 
+template <class S> static int launch_lane_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    if constexpr (LaneShape<S>::supported) {
+        hipLaunchKernelGGL(acme_lane_kernel<S>, dim3(grid), dim3(LANE_BLOCK), lds_bytes, st, A);
+        return (int)hipGetLastError();
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+}
+template <class S> static const void *lane_fn() {
+    if constexpr (LaneShape<S>::supported) return (const void *)acme_lane_kernel<S>;
+    else return nullptr;
+}
+template <class S> static int lane_lds(bool caching) {
+    if constexpr (LaneShape<S>::supported) return LaneShape<S>::lds_doubles(caching);
+    else return 0;
+}
+
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
 #define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
     KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>, \
                 jac_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                             \
+                lane_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                            \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
+                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
+                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
                 &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                        \
-                &launch_jac_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
+                &launch_jac_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                    \
+                &launch_lane_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };

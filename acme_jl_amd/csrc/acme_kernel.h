@@ -147,8 +147,7 @@ ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 // 19 instructions with two short dependency chains instead of the ~40 of the general-purpose
 // library routine.  exp(+-inf) gives NaN here (the library gives inf / 0): both make the residual
 // non-finite only in states the solver has already lost.
-ACME_DEV double exp_junction(double x) {
-    const wv::ExpTab t = wv::load_exp_tab();   // the 16 constants, two scalar loads
+ACME_DEV double exp_junction(double x, const wv::ExpTab &t) {
     const double k = rint(x * t[0]);
     double r = fma(-k, t[1], x);
     r = fma(-k, t[2], r);
@@ -163,8 +162,7 @@ ACME_DEV double exp_junction(double x) {
 }
 // two exponentials at once: the same arithmetic as exp_junction on each argument, written out
 // in lockstep so that the two dependency chains interleave and the constants are loaded once
-ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb) {
-    const wv::ExpTab t = wv::load_exp_tab();
+ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb, const wv::ExpTab &t) {
     const double ka = rint(xa * t[0]), kb = rint(xb * t[0]);
     double ra = fma(-ka, t[1], xa), rb = fma(-kb, t[1], xb);
     ra = fma(-ka, t[2], ra);
@@ -184,6 +182,9 @@ ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb) {
     ea = ldexp(pa, (int)wv::clamp_s(ka, t[14], t[15]));
     eb = ldexp(pb, (int)wv::clamp_s(kb, t[14], t[15]));
 }
+// ... with the 16 constants fetched on the spot (two scalar loads per call)
+ACME_DEV double exp_junction(double x) { return exp_junction(x, wv::load_exp_tab()); }
+ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb) { exp_junction2(xa, xb, ea, eb, wv::load_exp_tab()); }
 ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 
 // ---------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ struct Packed {
     Dims shape{};   // instantiated kernel shape
     Dims actual{};  // the model's own dimensions
     std::vector<double> image, rowc, init_state;
+    std::vector<double> lanec;   // LaneLayout block (models with one nonlinear sub-problem)
     std::vector<int> rowi;
     int nterms = 2, has_bjt = 0, rare_kinds = 0;
 };
@@ -356,6 +357,38 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
                     P.image[base + L.pexpr + ((size_t)t * S.np + j) * GROUP + pos] = pexpp[(size_t)j * S.nq + tc];
                 P.image[base + L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
             }
+    }
+    // the lane-per-instance kernel's constant block (see LaneLayout): regrouped copies of the above
+    P.lanec.clear();
+    if (m.subs.size() == 1 && !S.rare) {
+        const LaneLayout ll = make_lane_layout(S.nn, S.np, S.nx, S.nu, S.ny);
+        P.lanec.assign(ll.total, 0.0);
+        const int base = L.sub0;
+        for (int r = 0; r < S.nn; ++r) {
+            double *row = &P.lanec[(size_t)r * ll.row];
+            for (int t = 0; t < 3; ++t) {
+                row[ll.q0 + t] = P.image[base + L.q0r + (size_t)t * GROUP + r];
+                for (int j = 0; j < S.np; ++j) row[ll.pexp + t * S.np + j] = P.image[base + L.pexpr + ((size_t)t * S.np + j) * GROUP + r];
+                for (int j = 0; j < S.nn; ++j) row[ll.fq + t * S.nn + j] = P.image[base + L.fqr + ((size_t)t * S.nn + j) * GROUP + r];
+            }
+            for (int c = UR_SA; c <= UR_W1; ++c) row[ll.ur + c - UR_SA] = P.rowc[(size_t)c * GROUP + r];
+            row[ll.kind] = (double)P.rowi[0 * GROUP + r];
+        }
+        for (int i = 0; i < S.np; ++i) {
+            double *row = &P.lanec[ll.p0 + (size_t)i * ll.pstr];
+            for (int j = 0; j < S.nx; ++j) row[j] = P.image[base + L.dq + (size_t)j * S.np + i];
+            for (int k = 0; k < S.nu; ++k) row[S.nx + k] = P.image[base + L.eq + (size_t)k * S.np + i];
+        }
+        for (int which = 0; which < 2; ++which) {       // 0: y rows, 1: x rows
+            const int rows = which ? S.nx : S.ny, r0 = which ? 0 : S.nx;   // rows of [a; dy] etc.: x rows first, then y rows
+            for (int i = 0; i < rows; ++i) {
+                double *row = &P.lanec[(which ? ll.x0 : ll.y0) + (size_t)i * ll.xstr];
+                row[0] = P.image[L.x0 + r0 + i];
+                for (int j = 0; j < S.nx; ++j) row[1 + j] = P.image[L.a + (size_t)j * L.ld + r0 + i];
+                for (int k = 0; k < S.nu; ++k) row[1 + S.nx + k] = P.image[L.b + (size_t)k * L.ld + r0 + i];
+                for (int j = 0; j < S.nn; ++j) row[1 + S.nx + S.nu + j] = P.image[L.c + (size_t)j * L.ld + r0 + i];
+            }
+        }
     }
     return true;
 }

@@ -198,6 +198,14 @@ ACME_DEV void lds_max(long long *p, long long v) {
     (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// A pointer to memory that nothing writes during the launch, about to be read with wave-uniform
+// addresses: as a constant-address-space pointer (same addresses as global memory on gfx9) its loads
+// are invariant and go through the scalar unit (s_load_*, results in SGPRs) instead of 64 identical
+// per-lane vector loads.
+template <class T> ACME_DEV const __attribute__((address_space(4))) T *uniform_ro(const T *p) {
+    return (const __attribute__((address_space(4))) T *)p;
+}
+
 // scheduling fence: nothing is moved across (used to keep a batch of DPP broadcasts ahead of
 // the FMAs that consume them: a dependent dpp->fma pair costs ~17 cycles, batched ~9)
 ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -14,6 +14,7 @@
 
 #include "../../include/acme_hip.h"
 #include "../../acme_jl_amd/csrc/acme_kernel.h"
+#include "../../acme_jl_amd/csrc/acme_lane_kernel.h"
 #include "../../acme_jl_amd/csrc/acme_pack.h"
 
 using namespace acme;
@@ -114,10 +115,12 @@ void run_block(int bid, void (*entry)(void *), void *arg) {
 // ------------------------------------------------------------------------------------------
 struct KernelEntry {
     Dims d;
-    const void *fn, *fn_jac;
+    const void *fn, *fn_jac, *fn_lane;
     int lds_shared, lds_per_inst, state;
+    int lds_lane_plain, lds_lane_caching;
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
+    int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
 };
 
 struct LaunchCtx {
@@ -135,24 +138,39 @@ template <class S> static void fiber_entry_jac(void *p) {
     if constexpr (S::NN > 0) wave_main<S, MODE_JAC>(*c->A, c->lds);
 }
 
-template <class S, bool JAC> static int launch_any(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
+template <class S> static void fiber_entry_lane(void *p) {
+    LaunchCtx *c = (LaunchCtx *)p;
+    if constexpr (LaneShape<S>::supported) lane_main<S>(*c->A, c->lds);
+}
+
+// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel
+template <class S, int KIND> static int launch_any(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
+    static_assert(emu::BLOCK == LANE_BLOCK && emu::BLOCK == WAVES_PER_BLOCK * 64, "one emulated block = one kernel block");
     std::vector<double> lds(lds_bytes / sizeof(double) + 64);
     LaunchCtx c{&A, lds.data()};
     for (unsigned b = 0; b < grid; ++b) {
         // poison the LDS with NaNs: a kernel reading uninitialised LDS into a result shows up
         for (auto &v : lds) v = std::nan("");
-        emu::run_block((int)b, JAC ? &fiber_entry_jac<S> : &fiber_entry<S>, &c);
+        emu::run_block((int)b, KIND == 1 ? &fiber_entry_jac<S> : KIND == 2 ? &fiber_entry_lane<S> : &fiber_entry<S>, &c);
     }
     return 0;
+}
+template <class S> static int lane_lds(bool caching) {
+    if constexpr (LaneShape<S>::supported) return LaneShape<S>::lds_doubles(caching);
+    else return 0;
 }
 
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
 #define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false), \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, nullptr,            \
+                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
-                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, false>,                                   \
-                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, true>},
+                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
+                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
+                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 0>,                                       \
+                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 1>,                                       \
+                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 2>},
         ACME_EMU_SHAPES(ACME_X)
 #undef ACME_X
     };

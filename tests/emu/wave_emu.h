@@ -244,6 +244,7 @@ ACME_DEV ExpTab load_exp_tab() {
                    2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03,
                    8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, -2100.0, 2100.0}};
 }
+template <class T> ACME_DEV const T *uniform_ro(const T *p) { return p; }
 ACME_DEV void sched_fence() {}
 ACME_DEV void lds_add(long long *p, long long v) { *p += v; }
 ACME_DEV void lds_max(long long *p, long long v) { if (v > *p) *p = v; }
