@@ -479,8 +479,11 @@ def main():
                 / (last_ms * 1e-3) / 1e12 if model.subs else None,
                 "fp64_peak_tflops": FP64_PEAK_TFLOPS,
                 "valu_issue_frac": pmc_valu_issue_frac(args.workload, n_per_gpu, T),
+                "valu_issue_profiled_kernel_ms": (pmc_record(args.workload, n_per_gpu, T) or {}).get("kernel_avg_ms_profiled"),
                 "valu_issue_note": "VALU wave-instructions issued / (1024 SIMDs x cycles / 4), from the committed "
-                                   "rocprofv3 PMC pass of this workload (profiles/pmc_traffic.json); null if none",
+                                   "rocprofv3 PMC pass of this workload (profiles/pmc_traffic.json; instructions and cycles "
+                                   "are means over the same profiled launches, whose mean duration is "
+                                   "valu_issue_profiled_kernel_ms -- warm-up launches included, hence above kernel_ms); null if none",
             },
         }
         if out["roofline"]["fp64_tflops"] is not None:
