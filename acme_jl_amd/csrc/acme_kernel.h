@@ -192,12 +192,17 @@ ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 // ---------------------------------------------------------------------------------------
 template <int NN> struct RowLU {
     // Threshold partial pivoting: the row already sitting in pivot position is kept as long as no
-    // later row would need a multiplier larger than this (element growth per step <= 1 + 4, the
-    // usual relaxed-pivoting trade; the reference's strict rule is the threshold 1).  With the
-    // strict rule ~5 % of the solves re-learnt the row order only because two candidates of
-    // nearly equal size had swapped ranks: +10 % run time for differences at rounding level.
-    // 4.0 is an inline constant of the ISA.
-        static constexpr double PIVOT_THRESHOLD = 4.0;
+    // later row would need a multiplier larger than this, i.e. as long as |pivot| >= u * max with
+    // u = 1/8 -- the relaxed-pivoting trade sparse direct solvers make with u = 0.1 (and the
+    // reference's own front end: gensolve, src/ACME.jl:733); the reference's setlhs! is u = 1.  With the
+    // strict rule ~5 % of the solves re-learnt the row order only because two candidates of nearly
+    // equal size had swapped ranks: +10 % run time for differences at rounding level; 4 -> 8 buys
+    // another 4.5 % (16 nothing more), with outputs equal to 12 digits and identical iteration
+    // counts on every parity case (tests/solver_pins.py sweeps matrices built to separate the rules).
+#ifndef ACME_PIVOT_THRESHOLD
+#define ACME_PIVOT_THRESHOLD 8.0
+#endif
+        static constexpr double PIVOT_THRESHOLD = ACME_PIVOT_THRESHOLD;
 
     // Gauss-Jordan elimination of [A | b | C] in the CURRENT row order, without looking for
     // pivots -- valid whenever the rows already sit in (threshold-)pivot order, which is the

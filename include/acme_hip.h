@@ -109,7 +109,7 @@ int acme_model_add_subproblem(acme_model *m, int nn, int nq, int np, const doubl
                               const int *elem_roff, const double *elem_par);
 /* optional performance hint: order[pos] = residual row (0-based, in element-table order)
  * handled by lane `pos` when a batch is created.  The elimination keeps the row sitting in pivot
- * position while every multiplier satisfies |l| <= 4 (threshold partial pivoting; the
+ * position while every multiplier satisfies |l| <= 8 (threshold partial pivoting; the
  * reference's setlhs!, src/solvers.jl:58-78, is the threshold 1) and only otherwise re-learns
  * the order with the reference's first-strict-maximum search; listing the equations in their
  * usual pivot order spares the first such searches.  Either way the factorisation is a valid LU

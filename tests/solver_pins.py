@@ -63,7 +63,7 @@ def check_reference_lu_cases(lib):
 
 
 def pivot_sweep_matrices(n, count, seed):
-    """Matrices on which threshold pivoting (|l| <= 4 keeps the row in place) and the reference's
+    """Matrices on which threshold pivoting (|l| <= 8 keeps the row in place) and the reference's
     strict first-maximum rule choose DIFFERENT row orders, plus ones that force interchanges on
     either rule, plus plain well-conditioned ones."""
     rng = np.random.default_rng(seed)
