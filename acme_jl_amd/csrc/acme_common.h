@@ -60,12 +60,44 @@ struct Dims {
 // tc[r][t]) the image holds  fqr[(t*nn + j)*16 + r] = fq[tc[r][t], j]  (likewise pexpr, q0r).
 // The lane that evaluates row r then reads consecutive addresses for fixed (t, j): no
 // indirection and no LDS bank conflicts (the plain fq[tc + j*nq] form was ~39 % conflicts).
+// On the big shapes (nn >= 8) columns are stored in PAIRS (Layout::gat): entries (t, j) and (t, j + 1),
+// j even, of one row sit next to each other, so that two of them come with ONE 16-byte LDS read per
+// lane (+5.4 % on the headline; the small shapes, with odd column counts to pad and few reads to
+// save, lose 0.2 ... 2.5 % and keep single columns) (ds_read_b128:
+// 3.5 ns per element with every SIMD busy against 6.7 ns for the ds_read2_b64 the compiler otherwise
+// merges neighbouring columns into; tools/ubench/ldsread.hip).
 struct Layout {
     int a, b, c, x0, dy, ey, fy, y0;            // shared, absolute offsets (dy.. = a.. + nx: extra rows)
     int ld;                                     // leading dimension of those matrices: nx + ny
     int sub0, sub_stride;                       // first sub-problem block, distance to the next
     int dq, eq, fqprev, pexpr, fqr, q0r;        // offsets relative to a sub-problem block
     int total;
+    int pairs;                                  // row-gathered copies stored in column pairs (single-sub-problem shapes with nn >= 8)
+    // index (relative to pexpr / fqr) of the row-gathered entry (t, j) of row r, n columns per term
+    ACME_HD constexpr int gat(int t, int j, int r, int n) const {
+        return pairs ? ((t * ((n + 1) / 2) + j / 2) * GROUP + r) * 2 + (j & 1) : (t * n + j) * GROUP + r;
+    }
+    ACME_HD constexpr int gat_size(int nt, int n) const { return nt * (pairs ? ((n + 1) / 2) * 2 : n) * GROUP; }
+    // The matrices of the linear update, [x0 | a | b | c] over [y0 | dy | ey | fy] (ld = nx + ny rows):
+    // image index of row `row` of combined column `col` (0: x0/y0, then the nx columns of a/dy, the nu
+    // of b/ey, the nz of c/fy).  linp: stored in column PAIRS at lin0 like the row-gathered copies
+    // (the one-pass update of the big shapes reads two columns per ds_read_b128); otherwise the
+    // separate column-major blocks a, b, c, x0.
+    int linp, lin0;
+    // [dq | eq] of a sub-problem block (np rows, nx + nu columns): column pairs at dq when `pairs`
+    ACME_HD constexpr int pq(int col, int row, int np, int nx) const {
+        if (pairs) return dq + ((col / 2) * GROUP + row) * 2 + (col & 1);
+        return col < nx ? dq + col * np + row : eq + (col - nx) * np + row;
+    }
+    ACME_HD constexpr int lin(int col, int row, int nx, int nu) const {
+        if (linp) return lin0 + ((col / 2) * GROUP + row) * 2 + (col & 1);
+        if (col == 0) return x0 + row;
+        col -= 1;
+        if (col < nx) return a + col * ld + row;
+        col -= nx;
+        if (col < nu) return b + col * ld + row;
+        return c + (col - nu) * ld + row;
+    }
 };
 
 ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int ny, int nt, int nsub) {
@@ -77,21 +109,27 @@ ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int
     const int ld = nx + ny;
     int o = 0;
     L.ld = ld;
-    L.a = o;    o += ld * nx;
-    L.b = o;    o += ld * nu;
-    L.c = o;    o += ld * nz;
-    L.x0 = o;   o += ld;
+    L.pairs = (nn >= 8 && nsub == 1) ? 1 : 0;     // (the 4-sub-problem shapes have no LDS to spare for the padding)
+    L.linp = (L.pairs && ld <= GROUP && nx > 0) ? 1 : 0;     // (on the small shapes: +-0, measured)
+    if (L.linp) {
+        L.lin0 = o; o += ((1 + nx + nu + nz + 1) / 2) * 2 * GROUP;
+    }
+    L.a = o;    o += L.linp ? 0 : ld * nx;
+    L.b = o;    o += L.linp ? 0 : ld * nu;
+    L.c = o;    o += L.linp ? 0 : ld * nz;
+    L.x0 = o;   o += L.linp ? 0 : ld;
     L.dy = L.a + nx;
     L.ey = L.b + nx;
     L.fy = L.c + nx;
     L.y0 = L.x0 + nx;
     L.sub0 = (o + 1) & ~1;
     int r = 0;
-    L.dq = r;     r += np * nx;
-    L.eq = r;     r += np * nu;
+    L.dq = r;     r += L.pairs ? ((nx + nu + 1) / 2) * 2 * GROUP : np * nx;   // see Layout::pq
+    L.eq = r;     r += L.pairs ? 0 : np * nu;
     L.fqprev = r; r += nsub > 1 ? np * nz : 0;   // only read by sub-problems after the first
-    L.pexpr = r;  r += nt * np * GROUP;
-    L.fqr = r;    r += nt * nn * GROUP;
+    r = (r + 1) & ~1;                                        // pairs start 16-byte aligned
+    L.pexpr = r;  r += L.gat_size(nt, np);                   // see Layout::gat
+    L.fqr = r;    r += L.gat_size(nt, nn);
     L.q0r = r;    r += nt * GROUP;
     L.sub_stride = (r + 1) & ~1;
     // tail padding: lanes beyond a matrix's row count read (finite) neighbours, never past

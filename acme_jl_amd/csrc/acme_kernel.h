@@ -98,8 +98,12 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
 #endif
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
     static constexpr int OS_MUL = 0, OS_DINV = NN, OS_TV = NN + 1, OS_PF = NN + 1 + NT;
-    static constexpr int OSLOTS = MULT ? NN + 1 + 2 * NT : NP;
+    static constexpr int OSLOTS = MULT ? (NN + 1 + 2 * NT + 1) & ~1 : NP;
     static constexpr int ORIGIN1 = OSLOTS * OSTRIDE;          // one sub-problem
+    // offset of slot s from the lane's position in the slab.  MULT: slots in PAIRS (two per
+    // ds_read_b128 when the extrapolation reads them back), a lane's position counts double
+    static constexpr int OPOS = MULT ? 2 : 1;
+    ACME_HD static constexpr int oslot(int s) { return MULT ? (s / 2) * 2 * OSTRIDE + (s & 1) : s * OSTRIDE; }
     static constexpr int ORIGIN = NSUBr * ORIGIN1 + GROUP;
     // solution cache of one sub-problem of one instance.  In LDS: cp[NP][CACHE] | count, head;
     // in HBM the same followed by cz[NN][CACHE] (see acme_common.h)
@@ -220,7 +224,8 @@ template <int NN> struct RowLU {
     // the same linear map can later be applied to another right-hand side (apply_stored): that is
     // all the solver needs of the factorisation at its extrapolation origin.
     // GJHEAD / SAFE0: see Shape.
-    template <int NC, bool STORE, int OS, bool GJHEAD, bool SAFE0>
+    // (slot s of the slab sits at slab[SLOT(s)]: Shape::oslot)
+    template <int NC, bool STORE, class SH, bool GJHEAD, bool SAFE0>
     static ACME_DEV unsigned long long solve_inplace(double (&a)[NN > 0 ? NN : 1], double &b,
                                                      double (&c)[NC > 0 ? NC : 1], double *slab, bool keep) {
         unsigned long long viol = 0;
@@ -248,7 +253,7 @@ template <int NN> struct RowLU {
             }
             const unsigned long long big = wv::ballot(fabs(nlm) > PIVOT_THRESHOLD);
             if constexpr (STORE) {
-                if (keep) slab[k * OS] = nlm;
+                if (keep) slab[SH::oslot(k)] = nlm;
             }
             // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
             viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
@@ -262,7 +267,7 @@ template <int NN> struct RowLU {
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
         if constexpr (STORE) {
-            if (keep) slab[NN * OS] = dinv;
+            if (keep) slab[SH::oslot(NN)] = dinv;
         }
         // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
         viol |= wv::ballot(!(b * 0.0 == 0.0));
@@ -273,12 +278,19 @@ template <int NN> struct RowLU {
     // operations, in the same order, the right-hand side would have seen riding along as an
     // augmented column.  Every step reads, through DPP, the register the previous step wrote: the
     // SAFE forms supply the two wait states.
-    template <int OS> static ACME_DEV void apply_stored(double &b, const double *slab) {
+    template <class SH> static ACME_DEV void apply_stored(double &b, const double *slab) {
+        double mul[NN + 2];                       // the row's multipliers and 1/pivot, two slots per LDS read
+        sfor<0, (NN + 2) / 2>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = 2 * decltype(kc)::value;
+            const wv::pair_t v = wv::ld2(&slab[SH::oslot(k)]);
+            mul[k] = v.lo;
+            mul[k + 1] = v.hi;
+        });
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
-            wv::fmac_bcast_self<k, true>(b, slab[k * OS]);
+            wv::fmac_bcast_self<k, true>(b, mul[k]);
         });
-        b *= slab[NN * OS];
+        b *= mul[NN];
     }
 
     // setlhs! with partial pivoting (first strict maximum, src/solvers.jl:58-78), run only to
@@ -528,12 +540,13 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     const bool valid = inst < A.n_inst;
 
     // ---- LDS carve-up -------------------------------------------------------------------
+    lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));   // the block's dynamic LDS starts at 0
     double *lds_img = lds;
     double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;        // [NSUB][ROWC_L*16]
     int *lds_rowi = (int *)(lds_rowc + NSUB * S::ROWC_L * GROUP);                  // [NSUB][ROWI*16]
     double *lds_scr = lds_rowc + NSUB * (S::ROWC_L * GROUP + S::ROWI_L * GROUP);
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
-    double *const ojp0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + grp * NN + lig;
+    double *const ojp0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + S::OPOS * (grp * NN + lig);
     double *const cache0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + WAVES_PER_BLOCK * S::ORIGIN + gib * S::CACHEI;
     // context of the sub-problem being solved (switched by enter_sub)
     double *ojp = ojp0;            // origin's J^-1 * Jp, row lig: [j * OS]
@@ -597,7 +610,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 constexpr int t = decltype(tc_)::value;
                 sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    fqreg[t][j] = Ms[L.fqr + (t * NN + j) * GROUP + rowid];
+                    fqreg[t][j] = Ms[L.fqr + L.gat(t, j, 0, NN) + (L.pairs ? 2 : 1) * rowid];
                 });
             });
         }
@@ -675,10 +688,21 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
             double acc = Ms[L.q0r + t * GROUP + rowid];
+            double pe[NPr + 1];                     // this row's pexp entries of term t, two per LDS read
+            if constexpr (L.pairs) {
+                sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * rowid]);
+                    pe[j] = v.lo;
+                    pe[j + 1] = v.hi;
+                });
+            } else {
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + rowid]; });
+            }
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (!S::FUSE) acc = fma(Ms[L.pexpr + (t * NP + j) * GROUP + rowid], pb[j], acc);
-                else wv::fmac_bcast<j>(acc, p, Ms[L.pexpr + (t * NP + j) * GROUP + rowid]);
+                if constexpr (!S::FUSE) acc = fma(pe[j], pb[j], acc);
+                else wv::fmac_bcast<j>(acc, p, pe[j]);
             });
             pf[t] = acc;
             wv::sched_fence();   // bound the number of LDS loads in flight (register pressure)
@@ -695,14 +719,21 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         if constexpr (!S::FUSE)
             sfor<0, NN>([&](auto jc) ACME_LAMBDA { zb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(zz); });
         // this row's fq entries (used twice: q = pf + fq*z here, J = Jq*fq below)
-        double fqv[NT][NNr];
+        double fqv[NT][NNr + 1];
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
-            sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (S::FQREG) fqv[t][j] = fqreg[t][j];
-                else fqv[t][j] = Ms[L.fqr + (t * NN + j) * GROUP + rowid];
-            });
+            if constexpr (S::FQREG) {
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = fqreg[t][decltype(jc)::value]; });
+            } else if constexpr (L.pairs) {
+                sfor<0, (NN + 1) / 2>([&](auto jc) ACME_LAMBDA {      // two columns per LDS read (Layout::gat)
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * rowid]);
+                    fqv[t][j] = v.lo;
+                    fqv[t][j + 1] = v.hi;
+                });
+            } else {
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = Ms[L.fqr + L.gat(t, decltype(jc)::value, 0, NN) + rowid]; });
+            }
         });
         if constexpr (!S::FQREG) wv::sched_fence();
         double e[NT];
@@ -775,15 +806,31 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
 
     // calc_Jp closure (src/ACME.jl:246-251): Jp row = Jq row * pexp
     auto calc_jp = [&](double (&jp)[NPr]) ACME_LAMBDA {
-        sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-            constexpr int j = decltype(jc)::value;
-            double acc = tv[0] * Ms[L.pexpr + j * GROUP + rowid];
-            sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
-                constexpr int t = decltype(tc_)::value;
-                acc = fma(tv[t], Ms[L.pexpr + (t * NP + j) * GROUP + rowid], acc);
+        if constexpr (L.pairs) {
+            sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = 2 * decltype(jc)::value;
+                const wv::pair_t v0 = wv::ld2(&Ms[L.pexpr + L.gat(0, j, 0, NP) + 2 * rowid]);
+                double a0 = tv[0] * v0.lo, a1 = tv[0] * v0.hi;
+                sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
+                    constexpr int t = decltype(tc_)::value;
+                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * rowid]);
+                    a0 = fma(tv[t], v.lo, a0);
+                    a1 = fma(tv[t], v.hi, a1);
+                });
+                jp[j] = a0;
+                if constexpr (j + 1 < NP) jp[j + 1] = a1;
             });
-            jp[j] = acc;
-        });
+        } else {
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                double acc = tv[0] * Ms[L.pexpr + L.gat(0, j, 0, NP) + rowid];
+                sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
+                    constexpr int t = decltype(tc_)::value;
+                    acc = fma(tv[t], Ms[L.pexpr + L.gat(t, j, 0, NP) + rowid], acc);
+                });
+                jp[j] = acc;
+            });
+        }
     };
 
     // After a pivoted factorisation the lane at position i holds what was row orig[i]: make
@@ -846,14 +893,14 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             const bool recording = wv::ballot(want) != 0ull;
             if (recording) {
                 if constexpr (S::MULT) {
-                    viol = LU::template solve_inplace<0, true, OS, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, want && lig < NN);
+                    viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, want && lig < NN);
                 } else {       // the columns of Jp ride along: jp <- J^-1 Jp
                     calc_jp(jp);
-                    viol = LU::template solve_inplace<NP, false, OS, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false);
+                    viol = LU::template solve_inplace<NP, false, S, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false);
                 }
                 ACME_T(TB_GJP);
             } else {
-                viol = LU::template solve_inplace<0, false, OS, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, false);
+                viol = LU::template solve_inplace<0, false, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, false);
                 ACME_T(TB_GJ0);
             }
             viol &= wv::ballot(act || force);   // the other instances' results are not used
@@ -869,8 +916,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                     if constexpr (S::MULT) {
                         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                             constexpr int t = decltype(tc_)::value;
-                            ojp[(S::OS_TV + t) * OS] = tv[t];
-                            ojp[(S::OS_PF + t) * OS] = pf[t];
+                            ojp[S::oslot(S::OS_TV + t)] = tv[t];
+                            ojp[S::oslot(S::OS_PF + t)] = pf[t];
                         });
                     } else {
                         sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
@@ -927,9 +974,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         if constexpr (S::MULT) {
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int tt = decltype(tc_)::value;
-                t = fma(ojp[(S::OS_TV + tt) * OS], pf[tt] - ojp[(S::OS_PF + tt) * OS], t);
+                t = fma(ojp[S::oslot(S::OS_TV + tt)], pf[tt] - ojp[S::oslot(S::OS_PF + tt)], t);
             });
-            LU::template apply_stored<OS>(t, ojp);
+            LU::template apply_stored<S>(t, ojp);
         } else {       // the slab holds J^-1 Jp, row lig
             const double dp = target - lp;
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
@@ -1067,7 +1114,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 }
                 calc_jp(jp);
                 dz = res;
-                const unsigned long long viol = LU::template solve_inplace<NP, false, OS, false, true>(a, dz, jp, ojp, false);
+                const unsigned long long viol = LU::template solve_inplace<NP, false, S, false, true>(a, dz, jp, ojp, false);
                 mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
                 if (viol != 0ull && phase == 0) {
                     relearn = mine;
@@ -1146,18 +1193,29 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 const bool alive = !dead;
                 // p = dq*x + eq*u + fqprev*z  (src/ACME.jl:678-686)
                 double p = 0.0;
+                double dqe[NX + NU + 1];       // row lig of [dq | eq], two columns per LDS read where stored in pairs
+                if constexpr (L.pairs) {
+                    sfor<0, (NX + NU + 1) / 2>([&](auto cc) ACME_LAMBDA {
+                        constexpr int c = 2 * decltype(cc)::value;
+                        const wv::pair_t v = wv::ld2(&Ms[L.pq(c, 0, NP, NX) + 2 * lig]);
+                        dqe[c] = v.lo;
+                        dqe[c + 1] = v.hi;
+                    });
+                } else {
+                    sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqe[decltype(cc)::value] = Ms[L.pq(decltype(cc)::value, 0, NP, NX) + lig]; });
+                }
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
                     if constexpr (!S::FUSE) {
                         double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
-                        p = fma(Ms[L.dq + j * NP + lig], xj, p);
+                        p = fma(dqe[j], xj, p);
                     } else {
-                        wv::fmac_bcast<j % GROUP>(p, x[j / GROUP], Ms[L.dq + j * NP + lig]);   // x: last sample's update
+                        wv::fmac_bcast<j % GROUP>(p, x[j / GROUP], dqe[j]);   // x: last sample's update
                     }
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    p = fma(Ms[L.eq + k * NP + lig], ubuf[m * NU + k], p);
+                    p = fma(dqe[NX + k], ubuf[m * NU + k], p);
                 });
                 sfor<0, s>([&](auto pc) ACME_LAMBDA {        // earlier sub-problems' z
                     constexpr int sp = decltype(pc)::value;
@@ -1246,23 +1304,37 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 // x = x0 + a*x + b*u + c*z (:708-714) in ONE pass: lanes < NX hold the rows of
                 // [a b c x0], lanes NX .. NX+NY-1 the rows of [dy ey fy y0] (same operations per row
                 // as two separate passes, half the instructions and LDS reads)
-                double acc = M[L.x0 + lig];
+                // the row of [x0 a b c] / [y0 dy ey fy] this lane owns: two columns per LDS read where the
+                // layout stores them in pairs (Layout::lin)
+                constexpr int NLC = 1 + NX + NU + S::NSUB * NN;
+                double w[NLC + 1];
+                if constexpr (L.linp) {
+                    sfor<0, (NLC + 1) / 2>([&](auto cc) ACME_LAMBDA {
+                        constexpr int c = 2 * decltype(cc)::value;
+                        const wv::pair_t v = wv::ld2(&M[L.lin(c, 0, NX, NU) + 2 * lig]);
+                        w[c] = v.lo;
+                        w[c + 1] = v.hi;
+                    });
+                } else {
+                    sfor<0, NLC>([&](auto cc) ACME_LAMBDA { w[decltype(cc)::value] = M[L.lin(decltype(cc)::value, 0, NX, NU) + lig]; });
+                }
+                double acc = w[0];
                 if constexpr (S::FUSE) wv::dpp_wait();    // zs[] was selected just above
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    if constexpr (!S::FUSE) acc = fma(M[L.a + j * LD + lig], wv::bcast16<j>(x[0]), acc);
-                    else wv::fmac_bcast<j>(acc, x[0], M[L.a + j * LD + lig]);
+                    if constexpr (!S::FUSE) acc = fma(w[1 + j], wv::bcast16<j>(x[0]), acc);
+                    else wv::fmac_bcast<j>(acc, x[0], w[1 + j]);
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    acc = fma(M[L.b + k * LD + lig], ubuf[m * NU + k], acc);
+                    acc = fma(w[1 + NX + k], ubuf[m * NU + k], acc);
                 });
                 sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
                     constexpr int s = decltype(sc)::value;
                     sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                         constexpr int j = decltype(jc)::value;
-                        if constexpr (!S::FUSE) acc = fma(M[L.c + (s * NN + j) * LD + lig], wv::bcast16<j>(zs[s]), acc);
-                        else wv::fmac_bcast<j>(acc, zs[s], M[L.c + (s * NN + j) * LD + lig]);
+                        if constexpr (!S::FUSE) acc = fma(w[1 + NX + NU + s * NN + j], wv::bcast16<j>(zs[s]), acc);
+                        else wv::fmac_bcast<j>(acc, zs[s], w[1 + NX + NU + s * NN + j]);
                     });
                 });
                 if (NY > 0 && lig >= NX && lig < NX + NY) ybuf[m * NY + lig - NX] = live ? acc : (double)NAN;

@@ -278,12 +278,18 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     const int NSUBr = S.nsub > 0 ? S.nsub : 1;
     const Layout L = make_layout(S.nn, S.nq, S.np, S.nx, S.nu, S.ny, NT, NSUBr);
     P.image.assign(L.total, 0.0);
-    put(P.image, L.a, L.ld, m.a, d.nx, d.nx);
-    put(P.image, L.b, L.ld, m.b, d.nx, d.nu);
-    put(P.image, L.x0, L.ld, m.x0, d.nx, 1);
-    put(P.image, L.dy, L.ld, m.dy, d.ny, d.nx);
-    put(P.image, L.ey, L.ld, m.ey, d.ny, d.nu);
-    put(P.image, L.y0, L.ld, m.y0, d.ny, 1);
+    // [x0 | a | b | c] over [y0 | dy | ey | fy]: through Layout::lin (x rows 0 .. nx-1 of the SHAPE, y rows after them)
+    auto lin = [&](int col, int row) -> double & { return P.image[L.lin(col, row, S.nx, S.nu)]; };
+    for (int i = 0; i < d.nx; ++i) {
+        lin(0, i) = m.x0[i];
+        for (int j = 0; j < d.nx; ++j) lin(1 + j, i) = m.a[(size_t)j * d.nx + i];
+        for (int k = 0; k < d.nu; ++k) lin(1 + S.nx + k, i) = m.b[(size_t)k * d.nx + i];
+    }
+    for (int i = 0; i < d.ny; ++i) {
+        lin(0, S.nx + i) = m.y0[i];
+        for (int j = 0; j < d.nx; ++j) lin(1 + j, S.nx + i) = m.dy[(size_t)j * d.ny + i];
+        for (int k = 0; k < d.nu; ++k) lin(1 + S.nx + k, S.nx + i) = m.ey[(size_t)k * d.ny + i];
+    }
     P.rowc.assign((size_t)NSUBr * ROWC * GROUP, 0.0);
     P.rowi.assign((size_t)NSUBr * ROWI * GROUP, 0);
     P.init_state.assign((size_t)S.nx + (size_t)NSUBr * (S.np + S.nn), 0.0);
@@ -296,11 +302,13 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         const int base = L.sub0 + (int)k * L.sub_stride;
         // c and fy: this sub-problem's z columns go to padded columns k*NN ...
         for (int j = 0; j < s->nn; ++j) {
-            for (int i = 0; i < d.nx; ++i) P.image[L.c + ((size_t)k * S.nn + j) * L.ld + i] = m.c[(size_t)(zoff[k] + j) * d.nx + i];
-            for (int i = 0; i < d.ny; ++i) P.image[L.fy + ((size_t)k * S.nn + j) * L.ld + i] = m.fy[(size_t)(zoff[k] + j) * d.ny + i];
+            for (int i = 0; i < d.nx; ++i) lin(1 + S.nx + S.nu + (int)k * S.nn + j, i) = m.c[(size_t)(zoff[k] + j) * d.nx + i];
+            for (int i = 0; i < d.ny; ++i) lin(1 + S.nx + S.nu + (int)k * S.nn + j, S.nx + i) = m.fy[(size_t)(zoff[k] + j) * d.ny + i];
         }
-        put(P.image, base + L.dq, S.np, s->dq, s->np, d.nx);
-        put(P.image, base + L.eq, S.np, s->eq, s->np, d.nu);
+        for (int i = 0; i < s->np; ++i) {      // [dq | eq] through Layout::pq
+            for (int j = 0; j < d.nx; ++j) P.image[base + L.pq(j, i, S.np, S.nx)] = s->dq[(size_t)j * s->np + i];
+            for (int kk = 0; kk < d.nu; ++kk) P.image[base + L.pq(S.nx + kk, i, S.np, S.nx)] = s->eq[(size_t)kk * s->np + i];
+        }
         for (size_t kp = 0; kp < k; ++kp)  // fqprev: columns of the earlier sub-problems
             for (int j = 0; j < m.subs[kp].nn; ++j)
                 for (int i = 0; i < s->np; ++i)
@@ -352,9 +360,9 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
             for (int t = 0; t < NT; ++t) {
                 int tc = rowi[(3 + t) * GROUP + pos];
                 for (int j = 0; j < S.nn; ++j)
-                    P.image[base + L.fqr + ((size_t)t * S.nn + j) * GROUP + pos] = fqp[(size_t)j * S.nq + tc];
+                    P.image[base + L.fqr + L.gat(t, j, pos, S.nn)] = fqp[(size_t)j * S.nq + tc];
                 for (int j = 0; j < S.np; ++j)
-                    P.image[base + L.pexpr + ((size_t)t * S.np + j) * GROUP + pos] = pexpp[(size_t)j * S.nq + tc];
+                    P.image[base + L.pexpr + L.gat(t, j, pos, S.np)] = pexpp[(size_t)j * S.nq + tc];
                 P.image[base + L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
             }
     }
@@ -368,25 +376,21 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
             double *row = &P.lanec[(size_t)r * ll.row];
             for (int t = 0; t < 3; ++t) {
                 row[ll.q0 + t] = P.image[base + L.q0r + (size_t)t * GROUP + r];
-                for (int j = 0; j < S.np; ++j) row[ll.pexp + t * S.np + j] = P.image[base + L.pexpr + ((size_t)t * S.np + j) * GROUP + r];
-                for (int j = 0; j < S.nn; ++j) row[ll.fq + t * S.nn + j] = P.image[base + L.fqr + ((size_t)t * S.nn + j) * GROUP + r];
+                for (int j = 0; j < S.np; ++j) row[ll.pexp + t * S.np + j] = P.image[base + L.pexpr + L.gat(t, j, r, S.np)];
+                for (int j = 0; j < S.nn; ++j) row[ll.fq + t * S.nn + j] = P.image[base + L.fqr + L.gat(t, j, r, S.nn)];
             }
             for (int c = UR_SA; c <= UR_W1; ++c) row[ll.ur + c - UR_SA] = P.rowc[(size_t)c * GROUP + r];
             row[ll.kind] = (double)P.rowi[0 * GROUP + r];
         }
         for (int i = 0; i < S.np; ++i) {
             double *row = &P.lanec[ll.p0 + (size_t)i * ll.pstr];
-            for (int j = 0; j < S.nx; ++j) row[j] = P.image[base + L.dq + (size_t)j * S.np + i];
-            for (int k = 0; k < S.nu; ++k) row[S.nx + k] = P.image[base + L.eq + (size_t)k * S.np + i];
+            for (int j = 0; j < S.nx + S.nu; ++j) row[j] = P.image[base + L.pq(j, i, S.np, S.nx)];
         }
         for (int which = 0; which < 2; ++which) {       // 0: y rows, 1: x rows
             const int rows = which ? S.nx : S.ny, r0 = which ? 0 : S.nx;   // rows of [a; dy] etc.: x rows first, then y rows
             for (int i = 0; i < rows; ++i) {
                 double *row = &P.lanec[(which ? ll.x0 : ll.y0) + (size_t)i * ll.xstr];
-                row[0] = P.image[L.x0 + r0 + i];
-                for (int j = 0; j < S.nx; ++j) row[1 + j] = P.image[L.a + (size_t)j * L.ld + r0 + i];
-                for (int k = 0; k < S.nu; ++k) row[1 + S.nx + k] = P.image[L.b + (size_t)k * L.ld + r0 + i];
-                for (int j = 0; j < S.nn; ++j) row[1 + S.nx + S.nu + j] = P.image[L.c + (size_t)j * L.ld + r0 + i];
+                for (int c = 0; c < 1 + S.nx + S.nu + S.nn; ++c) row[c] = lin(c, r0 + i);
             }
         }
     }

@@ -206,6 +206,14 @@ template <class T> ACME_DEV const __attribute__((address_space(4))) T *uniform_r
     return (const __attribute__((address_space(4))) T *)p;
 }
 
+// two neighbouring doubles of LDS (16-byte aligned) with one ds_read_b128
+struct pair_t { double lo, hi; };
+ACME_DEV pair_t ld2(const double *p) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t v = *reinterpret_cast<const d2_t *>(__builtin_assume_aligned(p, 16));
+    return pair_t{v.x, v.y};
+}
+
 // scheduling fence: nothing is moved across (used to keep a batch of DPP broadcasts ahead of
 // the FMAs that consume them: a dependent dpp->fma pair costs ~17 cycles, batched ~9)
 ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -245,6 +245,8 @@ ACME_DEV ExpTab load_exp_tab() {
                    8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, -2100.0, 2100.0}};
 }
 template <class T> ACME_DEV const T *uniform_ro(const T *p) { return p; }
+struct pair_t { double lo, hi; };
+ACME_DEV pair_t ld2(const double *p) { return pair_t{p[0], p[1]}; }
 ACME_DEV void sched_fence() {}
 ACME_DEV void lds_add(long long *p, long long v) { *p += v; }
 ACME_DEV void lds_max(long long *p, long long v) { if (v > *p) *p = v; }
