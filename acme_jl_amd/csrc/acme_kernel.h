@@ -355,7 +355,8 @@ ACME_DEV void eval_row_unified(const RowDesc &rd, const double (&e)[NT], double 
     static_assert(NT >= 3, "unified rows use three q entries");
     const double cA = rd.k[UR_CA - UR_SA], cB = rd.k[UR_CB - UR_SA], dA = rd.k[UR_DA - UR_SA],
                  dB = rd.k[UR_DB - UR_SA], h = rd.k[UR_H - UR_SA];
-    // (the non-RARE kernels stage only UR_SA.. in LDS: rd.rc is based at UR_SA)
+    // (the non-RARE kernels stage only UR_SA.. in LDS: rd.rc is based at UR_SA; fetching these five
+    // as three pairs was tried: +-0)
     const double g0 = rd.rc[(UR_G0 - UR_SA) * GROUP], g1 = rd.rc[(UR_G1 - UR_SA) * GROUP],
                  g2 = rd.rc[(UR_G2 - UR_SA) * GROUP], w0 = rd.rc[(UR_W0 - UR_SA) * GROUP],
                  w1 = rd.rc[(UR_W1 - UR_SA) * GROUP];
@@ -687,7 +688,10 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         }
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
-            double acc = Ms[L.q0r + t * GROUP + rowid];
+            // (pair layout with an odd np: the pad column of the last pair holds q0, see acme_pack.h)
+            constexpr bool q0_in_pad = L.pairs && (NP % 2 == 1);
+            double acc = 0.0;
+            if constexpr (!q0_in_pad) acc = Ms[L.q0r + t * GROUP + rowid];
             double pe[NPr + 1];                     // this row's pexp entries of term t, two per LDS read
             if constexpr (L.pairs) {
                 sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
@@ -699,6 +703,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             } else {
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + rowid]; });
             }
+            if constexpr (q0_in_pad) acc = pe[NP];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (!S::FUSE) acc = fma(pe[j], pb[j], acc);
@@ -972,9 +977,17 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         // entries, which set_p has just formed; then the origin's recorded elimination.
         double t = 0.0;
         if constexpr (S::MULT) {
+            double otp[2 * NT + 2];                 // the origin's Jq non-zeros and pfull entries, two slots per LDS read
+            constexpr int s0 = S::OS_TV & ~1;
+            sfor<0, (S::OS_PF + NT - s0 + 1) / 2>([&](auto cc) ACME_LAMBDA {
+                constexpr int c = 2 * decltype(cc)::value;
+                const wv::pair_t v = wv::ld2(&ojp[S::oslot(s0 + c)]);
+                otp[c] = v.lo;
+                otp[c + 1] = v.hi;
+            });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int tt = decltype(tc_)::value;
-                t = fma(ojp[S::oslot(S::OS_TV + tt)], pf[tt] - ojp[S::oslot(S::OS_PF + tt)], t);
+                t = fma(otp[S::OS_TV - s0 + tt], pf[tt] - otp[S::OS_PF - s0 + tt], t);
             });
             LU::template apply_stored<S>(t, ojp);
         } else {       // the slab holds J^-1 Jp, row lig
@@ -1182,6 +1195,18 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         int cnt = (int)((T - n0 < S::CH) ? (T - n0) : S::CH);
         for (int m = 0; m < cnt; ++m) {
             const long long n = A.sample_base + n0 + m;
+            // this sample's inputs, read from the tile ONCE (p and the y/x update both use them)
+            double us[NU > 0 ? NU + 1 : 1];
+            if constexpr (L.pairs && NU % 2 == 0 && NU > 0) {
+                sfor<0, NU / 2>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = 2 * decltype(kc)::value;
+                    const wv::pair_t v = wv::ld2(&ubuf[m * NU + k]);
+                    us[k] = v.lo;
+                    us[k + 1] = v.hi;
+                });
+            } else {
+                sfor<0, NU>([&](auto kc) ACME_LAMBDA { us[decltype(kc)::value] = ubuf[m * NU + decltype(kc)::value]; });
+            }
             ACME_T(TB_POST);
             // the nonlinear sub-problems, one after another: later ones see the solutions of the
             // earlier ones through fqprev (src/ACME.jl:675-697)
@@ -1215,7 +1240,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    p = fma(dqe[NX + k], ubuf[m * NU + k], p);
+                    p = fma(dqe[NX + k], us[k], p);
                 });
                 sfor<0, s>([&](auto pc) ACME_LAMBDA {        // earlier sub-problems' z
                     constexpr int sp = decltype(pc)::value;
@@ -1327,7 +1352,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    acc = fma(w[1 + NX + k], ubuf[m * NU + k], acc);
+                    acc = fma(w[1 + NX + k], us[k], acc);
                 });
                 sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
                     constexpr int s = decltype(sc)::value;
@@ -1349,7 +1374,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    yy = fma(M[L.ey + k * LD + lig], ubuf[m * NU + k], yy);
+                    yy = fma(M[L.ey + k * LD + lig], us[k], yy);
                 });
                 sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
                     constexpr int s = decltype(sc)::value;
@@ -1378,7 +1403,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
-                    double uk = ubuf[m * NU + k];
+                    double uk = us[k];
                     sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
                         constexpr int s = decltype(sc)::value;
                         xn[s] = fma(M[L.b + k * LD + s * GROUP + lig], uk, xn[s]);

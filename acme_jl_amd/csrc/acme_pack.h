@@ -364,6 +364,8 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
                 for (int j = 0; j < S.np; ++j)
                     P.image[base + L.pexpr + L.gat(t, j, pos, S.np)] = pexpp[(size_t)j * S.nq + tc];
                 P.image[base + L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
+                if (L.pairs && (S.np % 2 == 1))     // the pad column of the last pexp pair: q0 comes with the pair read
+                    P.image[base + L.pexpr + L.gat(t, S.np, pos, S.np)] = q0p[tc];
             }
     }
     // the lane-per-instance kernel's constant block (see LaneLayout): regrouped copies of the above
