@@ -73,11 +73,16 @@ struct Layout {
     int dq, eq, fqprev, pexpr, fqr, q0r;        // offsets relative to a sub-problem block
     int total;
     int pairs;                                  // row-gathered copies stored in column pairs (single-sub-problem shapes with nn >= 8)
+    // rows per column of the row-gathered copies: nn + 1 where that is less than the 16 lanes -- the
+    // residual rows and one all-zero row, which the lanes beyond nn read (Monte-Carlo batches keep 16
+    // private images per block in LDS: the copies are two thirds of an image)
+    int gs;
     // index (relative to pexpr / fqr) of the row-gathered entry (t, j) of row r, n columns per term
     ACME_HD constexpr int gat(int t, int j, int r, int n) const {
-        return pairs ? ((t * ((n + 1) / 2) + j / 2) * GROUP + r) * 2 + (j & 1) : (t * n + j) * GROUP + r;
+        return pairs ? ((t * ((n + 1) / 2) + j / 2) * GROUP + r) * 2 + (j & 1) : (t * n + j) * gs + r;
     }
-    ACME_HD constexpr int gat_size(int nt, int n) const { return nt * (pairs ? ((n + 1) / 2) * 2 : n) * GROUP; }
+    ACME_HD constexpr int gat_size(int nt, int n) const { return pairs ? nt * ((n + 1) / 2) * 2 * GROUP : nt * n * gs; }
+    ACME_HD constexpr int q0i(int t, int r) const { return q0r + t * gs + r; }
     // The matrices of the linear update, [x0 | a | b | c] over [y0 | dy | ey | fy] (ld = nx + ny rows):
     // image index of row `row` of combined column `col` (0: x0/y0, then the nx columns of a/dy, the nu
     // of b/ey, the nz of c/fy).  linp: stored in column PAIRS at lin0 like the row-gathered copies
@@ -110,6 +115,7 @@ ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int
     int o = 0;
     L.ld = ld;
     L.pairs = (nn >= 8 && nsub == 1) ? 1 : 0;     // (the 4-sub-problem shapes have no LDS to spare for the padding)
+    L.gs = (L.pairs || nn + 1 >= GROUP) ? GROUP : nn + 1;
     L.linp = (L.pairs && ld <= GROUP && nx > 0) ? 1 : 0;     // (on the small shapes: +-0, measured)
     if (L.linp) {
         L.lin0 = o; o += ((1 + nx + nu + nz + 1) / 2) * 2 * GROUP;
@@ -130,7 +136,7 @@ ACME_HD constexpr Layout make_layout(int nn, int nq, int np, int nx, int nu, int
     r = (r + 1) & ~1;                                        // pairs start 16-byte aligned
     L.pexpr = r;  r += L.gat_size(nt, np);                   // see Layout::gat
     L.fqr = r;    r += L.gat_size(nt, nn);
-    L.q0r = r;    r += nt * GROUP;
+    L.q0r = r;    r += nt * L.gs;
     L.sub_stride = (r + 1) & ~1;
     // tail padding: lanes beyond a matrix's row count read (finite) neighbours, never past
     // the end of the image

@@ -50,6 +50,27 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int NXS = (NX + GROUP - 1) / GROUP;  // states per lane
     static constexpr int NUR = NU > 0 ? NU : 1;           // prefetch registers per lane
     static constexpr Layout L = make_layout(NN, NQ, NP, NX, NU, NY, RARE_ != 0 ? 4 : 3, NSUBr);
+    // The row of [x0 a b c; y0 dy ey fy] a lane applies every sample (NLC doubles), and its row of
+    // [dq eq], are the same for the whole launch: the small shapes keep them in REGISTERS, loaded once
+    // from the image in HBM (the big shape has no registers to spare and reads them as LDS pairs).
+    // That takes NLC + NX + NU LDS reads out of every sample -- and the linear part out of the image
+    // a block stages: with 16 private images per block (Monte-Carlo batches) what is left of a
+    // fixed-pot superover image is 2.7 KB instead of 7.6, two blocks fit a CU and the 8 192 instances
+    // of BASELINE config 4 run in ONE round at two waves per SIMD.
+    static constexpr int NLC = 1 + NX + NU + NSUBr * NN;
+#ifndef ACME_NO_LINREG
+    static constexpr bool LINREG = NX > 0 && NX + NY <= GROUP && !L.linp && NSUB == 1 && NLC <= 20;
+#else
+    static constexpr bool LINREG = false;
+#endif
+#ifndef ACME_NO_DQREG
+    static constexpr bool DQREG = LINREG && NP > 0 && NLC + NX + NU <= 24;     // (fixed-pot superover: 20 + 12, spills)
+#else
+    static constexpr bool DQREG = false;
+#endif
+    // what a block stages of a PRIVATE image: [IMG0, IMG0 + IMGN) (a shared image is staged whole)
+    static constexpr int IMG0 = LINREG ? L.sub0 + (DQREG ? L.pexpr : 0) : 0;
+    static constexpr int IMGN = L.total - IMG0;
     // samples staged per coalesced u / y transfer: 16, or 8 for the shapes with many inputs (LDS
     // per block decides whether two blocks fit a CU; a refill exposes ~1 us of HBM latency)
     static constexpr int CH = NU >= 4 ? CHUNK / 2 : CHUNK;
@@ -114,7 +135,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // the solution caches sit at the end of the block's LDS and are only allocated (and touched) when
     // the batch runs the caching solver
     ACME_HD static constexpr int lds_doubles(bool per_instance) {
-        return (per_instance ? INST_PER_BLOCK : 1) * L.total + NSUBr * (ROWC_L * GROUP + ROWI_L * GROUP) +
+        return (per_instance ? INST_PER_BLOCK * IMGN : L.total) + NSUBr * (ROWC_L * GROUP + ROWI_L * GROUP) +
                INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
 };
@@ -543,7 +564,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // ---- LDS carve-up -------------------------------------------------------------------
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));   // the block's dynamic LDS starts at 0
     double *lds_img = lds;
-    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK : 1) * L.total;        // [NSUB][ROWC_L*16]
+    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK * S::IMGN : L.total);  // [NSUB][ROWC_L*16]
     int *lds_rowi = (int *)(lds_rowc + NSUB * S::ROWC_L * GROUP);                  // [NSUB][ROWI*16]
     double *lds_scr = lds_rowc + NSUB * (S::ROWC_L * GROUP + S::ROWI_L * GROUP);
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
@@ -564,7 +585,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 long long ii = (long long)wv::bid() * INST_PER_BLOCK + g;
                 if (ii >= A.n_inst) ii = A.n_inst - 1;
                 const double *src = A.image + ii * A.image_stride;
-                for (int i = tid; i < L.total; i += nthreads) lds_img[g * L.total + i] = src[i];
+                for (int i = tid; i < S::IMGN; i += nthreads) lds_img[g * S::IMGN + i] = src[S::IMG0 + i];
             }
         }
         for (int s = 0; s < NSUB; ++s)     // only the constants this shape's row evaluation reads
@@ -574,7 +595,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     }
     wv::block_sync();
 
-    const double *M = lds_img + (per_inst ? gib * L.total : 0);   // this instance's image
+    // this instance's image (a private one: only offsets >= IMG0 are there)
+    const double *M = per_inst ? lds_img + (gib * S::IMGN - S::IMG0) : lds_img;
+    const double *Mg = A.image + (per_inst && valid ? inst * A.image_stride : 0);   // ... and in HBM
     const double *Ms = M + L.sub0;                                // current sub-problem block
     double *ubuf = lds_scr + gib * S::SCRATCH;
     double *ybuf = ubuf + S::UBUF;
@@ -596,6 +619,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // hint and then follows the LU: whenever a factorisation has to interchange rows, the
     // lanes ADOPT the pivoted order, so the next factorisation finds its pivots in place.
     int rowid = lig;
+    int grow = lig;      // ... and its row in the row-gathered copies (lanes beyond NN: the all-zero row, Layout::gs)
     RowDesc rd;
     double fqreg[S::FQREG ? NT : 1][S::FQREG ? NNr : 1];
     auto load_rowdesc = [&]() ACME_LAMBDA {
@@ -603,6 +627,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         rd.erow = rowi_s[1 * GROUP + rowid];
         rd.flags = rowi_s[2 * GROUP + rowid];
         rd.rc = rowc_s + rowid;            // rc[c * GROUP] = row constant RC0 + c
+        grow = (L.gs == GROUP || lig < NN) ? rowid : NN;
         // register-cached constants: the kind-by-kind evaluation (RARE shapes) wants rc[0..7],
         // the unified rows sA sB cA cB dA dB h
         sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
@@ -611,7 +636,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 constexpr int t = decltype(tc_)::value;
                 sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    fqreg[t][j] = Ms[L.fqr + L.gat(t, j, 0, NN) + (L.pairs ? 2 : 1) * rowid];
+                    fqreg[t][j] = Ms[L.fqr + L.gat(t, j, 0, NN) + (L.pairs ? 2 : 1) * grow];
                 });
             });
         }
@@ -691,17 +716,17 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             // (pair layout with an odd np: the pad column of the last pair holds q0, see acme_pack.h)
             constexpr bool q0_in_pad = L.pairs && (NP % 2 == 1);
             double acc = 0.0;
-            if constexpr (!q0_in_pad) acc = Ms[L.q0r + t * GROUP + rowid];
+            if constexpr (!q0_in_pad) acc = Ms[L.q0i(t, 0) + grow];
             double pe[NPr + 1];                     // this row's pexp entries of term t, two per LDS read
             if constexpr (L.pairs) {
                 sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = 2 * decltype(jc)::value;
-                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * rowid]);
+                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * grow]);
                     pe[j] = v.lo;
                     pe[j + 1] = v.hi;
                 });
             } else {
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + rowid]; });
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + grow]; });
             }
             if constexpr (q0_in_pad) acc = pe[NP];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
@@ -732,12 +757,12 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             } else if constexpr (L.pairs) {
                 sfor<0, (NN + 1) / 2>([&](auto jc) ACME_LAMBDA {      // two columns per LDS read (Layout::gat)
                     constexpr int j = 2 * decltype(jc)::value;
-                    const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * rowid]);
+                    const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * grow]);
                     fqv[t][j] = v.lo;
                     fqv[t][j + 1] = v.hi;
                 });
             } else {
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = Ms[L.fqr + L.gat(t, decltype(jc)::value, 0, NN) + rowid]; });
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = Ms[L.fqr + L.gat(t, decltype(jc)::value, 0, NN) + grow]; });
             }
         });
         if constexpr (!S::FQREG) wv::sched_fence();
@@ -814,11 +839,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         if constexpr (L.pairs) {
             sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = 2 * decltype(jc)::value;
-                const wv::pair_t v0 = wv::ld2(&Ms[L.pexpr + L.gat(0, j, 0, NP) + 2 * rowid]);
+                const wv::pair_t v0 = wv::ld2(&Ms[L.pexpr + L.gat(0, j, 0, NP) + 2 * grow]);
                 double a0 = tv[0] * v0.lo, a1 = tv[0] * v0.hi;
                 sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                     constexpr int t = decltype(tc_)::value;
-                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * rowid]);
+                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * grow]);
                     a0 = fma(tv[t], v.lo, a0);
                     a1 = fma(tv[t], v.hi, a1);
                 });
@@ -828,10 +853,10 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         } else {
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                double acc = tv[0] * Ms[L.pexpr + L.gat(0, j, 0, NP) + rowid];
+                double acc = tv[0] * Ms[L.pexpr + L.gat(0, j, 0, NP) + grow];
                 sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                     constexpr int t = decltype(tc_)::value;
-                    acc = fma(tv[t], Ms[L.pexpr + L.gat(t, j, 0, NP) + rowid], acc);
+                    acc = fma(tv[t], Ms[L.pexpr + L.gat(t, j, 0, NP) + grow], acc);
                 });
                 jp[j] = acc;
             });
@@ -1191,6 +1216,13 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         stage_u();
     }
 
+    // register-resident rows of the linear part (Shape::LINREG / DQREG)
+    double wreg[S::LINREG ? S::NLC : 1], dqreg[S::DQREG ? NX + NU : 1];
+    if constexpr (S::LINREG)
+        sfor<0, S::NLC>([&](auto cc) ACME_LAMBDA { wreg[decltype(cc)::value] = Mg[L.lin(decltype(cc)::value, 0, NX, NU) + lig]; });
+    if constexpr (S::DQREG)
+        sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqreg[decltype(cc)::value] = Mg[L.sub0 + L.pq(decltype(cc)::value, 0, NP, NX) + lig]; });
+
     for (long long n0 = 0; n0 < T; n0 += S::CH) {
         int cnt = (int)((T - n0 < S::CH) ? (T - n0) : S::CH);
         for (int m = 0; m < cnt; ++m) {
@@ -1226,6 +1258,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                         dqe[c] = v.lo;
                         dqe[c + 1] = v.hi;
                     });
+                } else if constexpr (S::DQREG) {
+                    sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqe[decltype(cc)::value] = dqreg[decltype(cc)::value]; });
                 } else {
                     sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqe[decltype(cc)::value] = Ms[L.pq(decltype(cc)::value, 0, NP, NX) + lig]; });
                 }
@@ -1331,7 +1365,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 // as two separate passes, half the instructions and LDS reads)
                 // the row of [x0 a b c] / [y0 dy ey fy] this lane owns: two columns per LDS read where the
                 // layout stores them in pairs (Layout::lin)
-                constexpr int NLC = 1 + NX + NU + S::NSUB * NN;
+                constexpr int NLC = S::NLC;
                 double w[NLC + 1];
                 if constexpr (L.linp) {
                     sfor<0, (NLC + 1) / 2>([&](auto cc) ACME_LAMBDA {
@@ -1340,6 +1374,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                         w[c] = v.lo;
                         w[c + 1] = v.hi;
                     });
+                } else if constexpr (S::LINREG) {
+                    sfor<0, NLC>([&](auto cc) ACME_LAMBDA { w[decltype(cc)::value] = wreg[decltype(cc)::value]; });
                 } else {
                     sfor<0, NLC>([&](auto cc) ACME_LAMBDA { w[decltype(cc)::value] = M[L.lin(decltype(cc)::value, 0, NX, NU) + lig]; });
                 }

@@ -363,7 +363,7 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
                     P.image[base + L.fqr + L.gat(t, j, pos, S.nn)] = fqp[(size_t)j * S.nq + tc];
                 for (int j = 0; j < S.np; ++j)
                     P.image[base + L.pexpr + L.gat(t, j, pos, S.np)] = pexpp[(size_t)j * S.nq + tc];
-                P.image[base + L.q0r + (size_t)t * GROUP + pos] = q0p[tc];
+                P.image[base + L.q0i(t, pos)] = q0p[tc];
                 if (L.pairs && (S.np % 2 == 1))     // the pad column of the last pexp pair: q0 comes with the pair read
                     P.image[base + L.pexpr + L.gat(t, S.np, pos, S.np)] = q0p[tc];
             }
@@ -377,7 +377,7 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
         for (int r = 0; r < S.nn; ++r) {
             double *row = &P.lanec[(size_t)r * ll.row];
             for (int t = 0; t < 3; ++t) {
-                row[ll.q0 + t] = P.image[base + L.q0r + (size_t)t * GROUP + r];
+                row[ll.q0 + t] = P.image[base + L.q0i(t, r)];
                 for (int j = 0; j < S.np; ++j) row[ll.pexp + t * S.np + j] = P.image[base + L.pexpr + L.gat(t, j, r, S.np)];
                 for (int j = 0; j < S.nn; ++j) row[ll.fq + t * S.nn + j] = P.image[base + L.fqr + L.gat(t, j, r, S.nn)];
             }

@@ -8,7 +8,16 @@
 // the np(model,k) pins of test/runtests.jl:699,724,734,744,777).
 #pragma once
 // clang-format off
-#ifdef ACME_DEV_SHAPES   /* developer builds (tools/isa.sh): only the headline shape, compiles in seconds */
+#if defined(ACME_DEV_SHAPES) && ACME_DEV_SHAPES + 0 == 2   /* developer builds (tools/isa.sh): one shape, compiles in seconds */
+#define ACME_SHAPES(X)                                                                     \
+    X( 2,  4,  1,  1, 1, 1, 0, 1)
+#elif defined(ACME_DEV_SHAPES) && ACME_DEV_SHAPES + 0 == 4
+#define ACME_SHAPES(X)                                                                     \
+    X( 7, 14,  5, 11, 1, 1, 0, 1)
+#elif defined(ACME_DEV_SHAPES) && ACME_DEV_SHAPES + 0 == 5
+#define ACME_SHAPES(X)                                                                     \
+    X( 4,  9,  3,  3, 2, 1, 0, 1)
+#elif defined(ACME_DEV_SHAPES)
 #define ACME_SHAPES(X)                                                                     \
     X(13, 29, 11, 11, 4, 1, 0, 1)
 #else
