@@ -36,6 +36,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_jac_kernel(KArgs
     wave_main<S, MODE_JAC>(A, acme_lds);
 }
 
+// ... and solve(solver, p), once per instance (wave_main MODE_SOLVE): the solver-plugin contract
+template <class S>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_solve_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S, MODE_SOLVE>(A, acme_lds);
+}
+
 // run! for small models, one lane per instance (acme_lane_kernel.h): one wave per SIMD is all these
 // batches offer, so the kernel is built for the shortest dependent chain per sample, not for occupancy
 template <class S>
@@ -46,12 +53,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
 
 struct KernelEntry {
     Dims d;
-    const void *fn, *fn_jac, *fn_lane;
+    const void *fn, *fn_jac, *fn_solve, *fn_lane;
     int lds_shared, lds_per_inst;  // doubles
     int state;                     // doubles of state per instance
     int lds_lane_plain, lds_lane_caching;   // doubles, lane kernel (0: shape not supported by it)
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
+    int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
 };
 
@@ -67,6 +75,20 @@ template <class S> static int launch_jac_shape(const KArgs &A, unsigned grid, si
     } else {
         return (int)hipErrorInvalidValue;      // linear models have no nonlinear solver
     }
+}
+template <class S> static int launch_solve_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    if constexpr (S::NN > 0 && !S::SOLVE_SPLIT) {
+        return launch_shape<S>(A, grid, lds_bytes, st);      // (A.p_in != nullptr tells the run kernel)
+    } else if constexpr (S::NN > 0) {
+        hipLaunchKernelGGL(acme_solve_kernel<S>, dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+        return (int)hipGetLastError();
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+}
+template <class S> static const void *solve_fn() {
+    if constexpr (S::NN > 0 && S::SOLVE_SPLIT) return (const void *)acme_solve_kernel<S>;
+    else return nullptr;
 }
 template <class S> static const void *jac_fn() {
     if constexpr (S::NN > 0) return (const void *)acme_jac_kernel<S>;
@@ -95,6 +117,7 @@ static const std::vector<KernelEntry> &kernel_table() {
 #define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
     KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>, \
                 jac_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                             \
+                solve_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                           \
                 lane_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                            \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
@@ -102,6 +125,7 @@ static const std::vector<KernelEntry> &kernel_table() {
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
                 &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                        \
                 &launch_jac_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                    \
+                &launch_solve_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                  \
                 &launch_lane_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
         ACME_SHAPES(ACME_X)
 #undef ACME_X

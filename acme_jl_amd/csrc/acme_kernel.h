@@ -108,14 +108,19 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     //           operation (the compiler may copy a row register just before it; it does on the
     //           small shapes, never on the big one -- tools/dpp_hazard_check.py proves which):  big +1 % without
     static constexpr bool FUSE = MULT, GJHEAD = MULT, SAFE0 = !MULT;
+    // solve(solver, p) (acme_batch_solve) as a kernel of its own (wave_main MODE_SOLVE), which takes its
+    // pointers and branches out of the run kernel: small shapes +1 .. +4 %, the big one -1.5 % (it keeps both in one)
+    static constexpr bool SOLVE_SPLIT = !MULT;
     // the row-gathered fq entries of this lane's residual row (NT x NN doubles, used twice per
     // evaluate!) stay in registers between the rare changes of the lane's row instead of being
     // re-read from LDS by every evaluate!: since the extrapolation origin moved to the recorded
     // elimination the headline shape has the registers for it (2 x 39 of 256, no spills)
-#ifndef ACME_FQREG     /* experiment: the register allocator answers with 371 spills (EXPERIMENTS.md) */
-    static constexpr bool FQREG = false;
-#else
+#ifdef ACME_FQREG      /* experiment on the big shape: the register allocator answers with 371 spills (EXPERIMENTS.md) */
     static constexpr bool FQREG = RARE_ == 0 && NSUB_ == 1 && NN_ * 3 <= 40;
+#elif defined(ACME_FQREG_SMALL)   /* ... and on the smallest ones: 63 spills on the birdie (232 registers without) */
+    static constexpr bool FQREG = RARE_ == 0 && NSUB_ == 1 && NN_ <= 4 && NN_ > 0;
+#else
+    static constexpr bool FQREG = false;
 #endif
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
     static constexpr int OS_MUL = 0, OS_DINV = NN, OS_TV = NN + 1, OS_PF = NN + 1 + NT;
@@ -541,10 +546,12 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, dou
 // ---------------------------------------------------------------------------------------
 // the per-wave time loop
 // ---------------------------------------------------------------------------------------
-// MODE_RUN: run! / solve (the hot kernel).  MODE_JAC: one pass that exports every instance's
+// MODE_RUN: run! (the hot kernel).  MODE_SOLVE: ONE solve(solver, p) per instance, the solver-plugin
+// contract (acme_batch_solve) -- the same code with the time loop cut down to the solve, as a kernel of
+// its own so that its pointers and branches stay out of the hot one.  MODE_JAC: one pass that exports every instance's
 // get_extrapolation_jacobian(solver) = -(J \ Jp) at its extrapolation origin (src/solvers.jl:198-201),
 // a separate, small kernel so that its extra registers and code stay out of the hot one.
-enum { MODE_RUN = 0, MODE_JAC = 1 };
+enum { MODE_RUN = 0, MODE_JAC = 1, MODE_SOLVE = 2 };
 template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
     constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT, NSUB = S::NSUBr;
@@ -1183,13 +1190,16 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     wv::wave_fence();
 
     // ---- time loop ----------------------------------------------------------------------
-    const bool solve_mode = A.p_in != nullptr;
+    // (the big shapes keep ONE kernel for both, told apart at run time by A.p_in: splitting them changed
+    // nothing but the register allocation of the hot kernel, for the worse -- -1.5 % on the headline)
+    const bool solve_mode = S::SOLVE_SPLIT ? MODE == MODE_SOLVE : A.p_in != nullptr;
     const long long T = solve_mode ? 1 : A.T;
     const int nu_io = A.nu_io, ny_io = A.ny_io;
     // u tile: fetched for chunk 0 before the loop and for chunk c+1 at the end of the LAST sample of
     // chunk c (after its y/x update, the last readers of the old tile).  The ~1 us of HBM latency is
     // exposed once per 16 samples (< 0.5 % of their run time); issuing the loads earlier kept the
-    // staging registers alive across the update and cost more in spill traffic than it hid.
+    // staging registers alive across the update and cost more in spill traffic than it hid (and on the
+    // small shapes, which have the registers, requesting the tile a whole chunk ahead gained nothing).
     // (Global pointers are recomputed here, once per 16 samples, for the same reason.)
     double upre[S::NUR];
     auto fetch_u = [&](long long n0) ACME_LAMBDA {
@@ -1222,6 +1232,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         sfor<0, S::NLC>([&](auto cc) ACME_LAMBDA { wreg[decltype(cc)::value] = Mg[L.lin(decltype(cc)::value, 0, NX, NU) + lig]; });
     if constexpr (S::DQREG)
         sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqreg[decltype(cc)::value] = Mg[L.sub0 + L.pq(decltype(cc)::value, 0, NP, NX) + lig]; });
+    // (arrived HERE: no wait for them inside the time loop, where a u tile may be in flight)
+    if constexpr (S::LINREG)
+        sfor<0, S::NLC>([&](auto cc) ACME_LAMBDA { wreg[decltype(cc)::value] = wv::keep(wreg[decltype(cc)::value]); });
+    if constexpr (S::DQREG)
+        sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqreg[decltype(cc)::value] = wv::keep(dqreg[decltype(cc)::value]); });
 
     for (long long n0 = 0; n0 < T; n0 += S::CH) {
         int cnt = (int)((T - n0 < S::CH) ? (T - n0) : S::CH);

@@ -350,7 +350,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                     const double tt = cpv[e][j] - target[j];
                     d = fma(tt, tt, d);
                 });
-                const bool c = e < ccount && d < best;
+                const bool c = (int)(e < ccount) & (int)(d < best);    // (&&: a branch per entry)
                 best = c ? d : best;
                 idx = c ? e : idx;
             });

@@ -115,11 +115,12 @@ void run_block(int bid, void (*entry)(void *), void *arg) {
 // ------------------------------------------------------------------------------------------
 struct KernelEntry {
     Dims d;
-    const void *fn, *fn_jac, *fn_lane;
+    const void *fn, *fn_jac, *fn_solve, *fn_lane;
     int lds_shared, lds_per_inst, state;
     int lds_lane_plain, lds_lane_caching;
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
+    int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
 };
 
@@ -138,12 +139,17 @@ template <class S> static void fiber_entry_jac(void *p) {
     if constexpr (S::NN > 0) wave_main<S, MODE_JAC>(*c->A, c->lds);
 }
 
+template <class S> static void fiber_entry_solve(void *p) {
+    LaunchCtx *c = (LaunchCtx *)p;
+    if constexpr (S::NN > 0) wave_main<S, S::SOLVE_SPLIT ? MODE_SOLVE : MODE_RUN>(*c->A, c->lds);
+}
+
 template <class S> static void fiber_entry_lane(void *p) {
     LaunchCtx *c = (LaunchCtx *)p;
     if constexpr (LaneShape<S>::supported) lane_main<S>(*c->A, c->lds);
 }
 
-// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel
+// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel, 3: solve kernel
 template <class S, int KIND> static int launch_any(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
     static_assert(emu::BLOCK == LANE_BLOCK && emu::BLOCK == WAVES_PER_BLOCK * 64, "one emulated block = one kernel block");
     std::vector<double> lds(lds_bytes / sizeof(double) + 64);
@@ -151,7 +157,7 @@ template <class S, int KIND> static int launch_any(const KArgs &A, unsigned grid
     for (unsigned b = 0; b < grid; ++b) {
         // poison the LDS with NaNs: a kernel reading uninitialised LDS into a result shows up
         for (auto &v : lds) v = std::nan("");
-        emu::run_block((int)b, KIND == 1 ? &fiber_entry_jac<S> : KIND == 2 ? &fiber_entry_lane<S> : &fiber_entry<S>, &c);
+        emu::run_block((int)b, KIND == 1 ? &fiber_entry_jac<S> : KIND == 2 ? &fiber_entry_lane<S> : KIND == 3 ? &fiber_entry_solve<S> : &fiber_entry<S>, &c);
     }
     return 0;
 }
@@ -163,13 +169,14 @@ template <class S> static int lane_lds(bool caching) {
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
 #define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, nullptr,            \
+    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, nullptr, nullptr,   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
                 &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 0>,                                       \
                 &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 1>,                                       \
+                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 3>,                                       \
                 &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 2>},
         ACME_EMU_SHAPES(ACME_X)
 #undef ACME_X

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
 mkdir -p gpurun_out/$tag
-export ACME_LANE_KERNEL=0
+export ACME_LANE_KERNEL=${LANE:-0}
 for wl in ${@:-superover_montecarlo birdie_grid diodeclipper_sweep}; do
   for so in build_variants/*.so; do
     r=$(ACME_HIP_LIB=$PWD/$so timeout ${BENCH_TIMEOUT:-120} python bench.py --no-cpu-baseline --workload $wl --steps ${STEPS:-3} --warmup ${WARMUP:-2} 2>&1 | tail -1)
