@@ -177,14 +177,16 @@ ACME_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 // 19 instructions with two short dependency chains instead of the ~40 of the general-purpose
 // library routine.  exp(+-inf) gives NaN here (the library gives inf / 0): both make the residual
 // non-finite only in states the solver has already lost.
-ACME_DEV double exp_junction(double x, const wv::ExpTab &t) {
+template <bool SC = true> ACME_DEV double exp_junction(double x, const wv::ExpTab &t) {
     const double k = rint(x * t[0]);
     double r = fma(-k, t[1], x);
     r = fma(-k, t[2], r);
     double p = fma(r, t[3], t[4]);                                                // 1/13!, 1/12!
     // (sconst: keep each coefficient a scalar operand of v_fma_f64 -- the compiler otherwise copies it
     // to vector registers to use the shorter v_fmac encoding, three instructions per step)
-    sfor<5, 14>([&](auto ic) ACME_LAMBDA { p = fma(p, r, wv::sconst(t[decltype(ic)::value])); });   // 1/11! .. 1/3!
+    // (SC = false: a table that stays in scalar registers for the whole kernel, as in the lane kernel --
+    // there the pinning costs an s_mov and a wait state per coefficient)
+    sfor<5, 14>([&](auto ic) ACME_LAMBDA { p = fma(p, r, SC ? wv::sconst(t[decltype(ic)::value]) : t[decltype(ic)::value]); });   // 1/11! .. 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

@@ -27,7 +27,10 @@
 namespace acme {
 
 constexpr int LANE_BLOCK = WAVES_PER_BLOCK * 64;   // instances per block (its waves never talk to each other)
-constexpr int LANE_TILE = 8;         // samples per u / y register tile (64 B per lane and input)
+#ifndef ACME_LANE_TILE
+#define ACME_LANE_TILE 8
+#endif
+constexpr int LANE_TILE = ACME_LANE_TILE;   // samples per u / y register tile (64 B per lane and input)
 
 template <class S> struct LaneShape {
     // LDS doubles per block: the stored p's of its instances' solution caches, cp[j][entry][lane]
@@ -127,19 +130,17 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     // v_readlane, one VALU instruction per use.
     constexpr LaneLayout LL = make_lane_layout(NN, NP, NX, NU, NY);
     double LCR[LL.total];                       // register-resident copy (same values in every lane)
-    int kinds[NN];                              // the rows' element kinds: wave-uniform (scalar registers)
     {
         const auto LC = wv::uniform_ro(A.lanec);
         // (wv::keep pins each value in a VECTOR register: left alone, the compiler notices that the
         // values are wave-uniform, moves them to scalar registers, runs out of those and brings them
         // back with one v_readlane per use)
         sfor<0, LL.total>([&](auto ec) ACME_LAMBDA { LCR[decltype(ec)::value] = wv::keep(LC[decltype(ec)::value]); });
-        const auto RI = wv::uniform_ro(A.rowi);           // RI[0 * GROUP + r]: kind of row r (an int: straight into an SGPR)
-        sfor<0, NN>([&](auto rc_) ACME_LAMBDA { kinds[decltype(rc_)::value] = RI[decltype(rc_)::value]; });
     }
     auto row_ptr = [&](int off) ACME_LAMBDA -> const double * { return LCR + off; };
     const wv::ExpTab etab = wv::load_exp_tab();  // the exponential's 16 constants: scalar registers, once
     const bool caching = A.solver == SOLVER_CACHING_HOMOTOPY;
+    const bool has_bjt = A.has_bjt != 0;
     double *cpl = lds + lane;                   // stored p's of this lane's cache: cpl[(j * CACHE + e) * LANE_BLOCK]
     double *cag = A.cache + ii * S::CACHEIH;    // HBM image of the cache (layout of acme_common.h)
 
@@ -208,14 +209,15 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 });
                 e[t] = acc;
             });
-            // unified element row (acme_common.h): the row's kind is the same for every lane, so the
-            // exponentials a kind does not have are skipped by scalar branches
-            const int kind = kinds[r];
+            // unified element row (acme_common.h).  One scalar branch per row -- does the MODEL have a
+            // BJT, i.e. can a second exponential be needed -- as in the 16-lane kernel (rows without a
+            // junction have sA = sB = 0: exp(0) - 1 = 0); a branch per row KIND (the kinds are
+            // wave-uniform too) came out as four branches a row, ~30 cycles each with nothing to hide them
             const auto U = R + (LL.ur - UR_SA);           // U[UR_x] = unified row constant x
             const double sA = U[UR_SA], sB = U[UR_SB];
-            double exA = 1.0, exB = 1.0;
-            if (kind == RK_BJT) exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etab);
-            else if (kind == RK_DIODE) exA = exp_junction(e[0] * sA, etab);
+            double exA, exB = 1.0;
+            if (has_bjt) exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etab);
+            else exA = exp_junction<false>(e[0] * sA, etab);
             const double cA = U[UR_CA], cB = U[UR_CB], dA = U[UR_DA], dB = U[UR_DB], h = U[UR_H];
             const double g0 = U[UR_G0], g1 = U[UR_G1], g2 = U[UR_G2], w0 = U[UR_W0], w1 = U[UR_W1];
             const double hw = h * fma(w1, e[2], w0);
@@ -397,13 +399,18 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     // appends its outputs to the back of ybuf (a handful of moves per sample, and ONE copy of the
     // sample body in the code instead of LANE_TILE).
     double ucur[LANE_TILE * NUr], unext[LANE_TILE * NUr], ybuf[LANE_TILE * NYr];
+    // (one predicate for the whole tile: samples past the end re-read the last one, inputs the model
+    // does not have re-read input 0 -- a branch per entry costs more than the loads)
     auto fetch = [&](long long n0, double (&dst)[LANE_TILE * NUr]) ACME_LAMBDA {
-        sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA {
-            constexpr int e = decltype(ec)::value;
-            const long long n = n0 + e / NUr;
-            const int k = e % NUr;
-            dst[e] = (valid && n < T && k < nu_io) ? ug[n * nu_io + k] : 0.0;
-        });
+        sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA { dst[decltype(ec)::value] = 0.0; });
+        if (valid && n0 < T) {
+            sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA {
+                constexpr int e = decltype(ec)::value;
+                const long long n = n0 + e / NUr;
+                const int k = e % NUr;
+                dst[e] = ug[(n < T ? n : T - 1) * nu_io + (k < nu_io ? k : 0)];
+            });
+        }
     };
     sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA { ybuf[decltype(ec)::value] = 0.0; });
     fetch(0, unext);
@@ -497,12 +504,16 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             sfor<0, NX>([&](auto ic) ACME_LAMBDA { x[decltype(ic)::value] = sel(live, xn[decltype(ic)::value], x[decltype(ic)::value]); });
         }
         // flush: the cnt outputs of this tile sit at the BACK of ybuf
-        sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA {
-            constexpr int e = decltype(ec)::value;
-            const int ms = e / NYr - (LANE_TILE - cnt);     // sample within the tile
-            const int k = e % NYr;
-            if (valid && ms >= 0 && k < ny_io) yg[(n0 + ms) * ny_io + k] = ybuf[e];
-        });
+        if (cnt == LANE_TILE && ny_io == NY) {                // the usual tile: one predicate for all of it
+            if (valid) sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA { yg[n0 * NY + decltype(ec)::value] = ybuf[decltype(ec)::value]; });
+        } else {
+            sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA {
+                constexpr int e = decltype(ec)::value;
+                const int ms = e / NYr - (LANE_TILE - cnt);     // sample within the tile
+                const int k = e % NYr;
+                if (valid && ms >= 0 && k < ny_io) yg[(n0 + ms) * ny_io + k] = ybuf[e];
+            });
+        }
     }
 
     // ---- write back ------------------------------------------------------------------------------
