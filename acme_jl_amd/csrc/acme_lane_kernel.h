@@ -34,7 +34,10 @@ constexpr int LANE_TILE = ACME_LANE_TILE;   // samples per u / y register tile (
 
 template <class S> struct LaneShape {
     // LDS doubles per block: the stored p's of its instances' solution caches, cp[j][entry][lane]
-    static constexpr int CACHE_LDS = S::NP * CACHE * LANE_BLOCK;
+    // ... unless they fit the registers (np <= 2: 16 or 32 doubles per lane; slots never written hold
+    // +inf, which no distance beats, so the scan does not look at the fill count either)
+    static constexpr bool CREG = S::NP * CACHE <= 32;
+    static constexpr int CACHE_LDS = CREG ? 0 : S::NP * CACHE * LANE_BLOCK;
     ACME_HD static constexpr int lds_doubles(bool caching) { return caching ? CACHE_LDS + 2 : 2; }
     static constexpr LaneLayout LL = make_lane_layout(S::NN, S::NP, S::NX, S::NU, S::NY);
     // the model's constants stay in REGISTERS for the whole launch (every lane holds the same
@@ -151,6 +154,10 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     sfor<0, NP>([&](auto c) ACME_LAMBDA { lp[decltype(c)::value] = valid ? st[NX + decltype(c)::value] : 0.0; });
     sfor<0, NN>([&](auto c) ACME_LAMBDA { lz[decltype(c)::value] = valid ? st[NX + NP + decltype(c)::value] : 0.0; z[decltype(c)::value] = 0.0; });
     int ccount = 0, chead = 0;
+    constexpr bool CREG = LaneShape<S>::CREG;
+    double cpr[CREG ? NPr : 1][CREG ? CACHE : 1];     // the stored p's, register-resident (LaneShape::CREG)
+    if constexpr (CREG)
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA { sfor<0, CACHE>([&](auto ec) ACME_LAMBDA { cpr[decltype(jc)::value][decltype(ec)::value] = (double)INFINITY; }); });
     if (caching) {
         if (valid) {
             const int *meta = reinterpret_cast<const int *>(cag + NP * CACHE);
@@ -158,7 +165,15 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             chead = meta[1];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                for (int e = 0; e < CACHE; ++e) cpl[(j * CACHE + e) * LANE_BLOCK] = cag[j * CACHE + e];
+                if constexpr (CREG) {
+                    sfor<0, CACHE>([&](auto ec) ACME_LAMBDA {
+                        constexpr int e = decltype(ec)::value;
+                        const double v = cag[j * CACHE + e];
+                        cpr[j][e] = e < ccount ? v : (double)INFINITY;
+                    });
+                } else {
+                    for (int e = 0; e < CACHE; ++e) cpl[(j * CACHE + e) * LANE_BLOCK] = cag[j * CACHE + e];
+                }
             });
         }
     }
@@ -308,23 +323,27 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             const bool want = act && finite && ok && small;
             const bool stop_bad = act && (!finite || !ok);
             conv = stop_bad ? small : conv;                     // hasconverged looks at resmaxabs alone
-            if (wv::ballot(want)) {                             // accepted iterate: the new extrapolation origin
-                double jp[NN][NPr];
-                calc_jp(jp);
-                sfor<0, NN>([&](auto ic) ACME_LAMBDA {
-                    constexpr int i = decltype(ic)::value;
-                    oipiv[i] = want ? ipiv[i] : oipiv[i];
-                    sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[i][decltype(jc)::value] = sel(want, jm[i][decltype(jc)::value], olu[i][decltype(jc)::value]); });
-                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[i][decltype(jc)::value] = sel(want, jp[i][decltype(jc)::value], ojp[i][decltype(jc)::value]); });
-                    lz[i] = sel(want, z[i], lz[i]);
-                });
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { lp[decltype(jc)::value] = sel(want, target[decltype(jc)::value], lp[decltype(jc)::value]); });
-            }
             accepted = accepted || want;
             const bool step = act && !stop_bad && !want;
             lane_lu_solve<NN>(jm, ipiv, dz);
             sfor<0, NN>([&](auto ic) ACME_LAMBDA { z[decltype(ic)::value] = sel(step, z[decltype(ic)::value] - dz[decltype(ic)::value], z[decltype(ic)::value]); });
             act = step && (its < A.maxiter);
+        }
+        // The accepted iterate is the new extrapolation origin (src/solvers.jl:227-233).  Taken HERE, once:
+        // a lane that has stopped keeps its z, so every later pass of the loop (run for the lanes still
+        // iterating) recomputes the same evaluate! and the same factors for it -- at the exit jm / ipiv / tv
+        // are those of every lane's last iterate.
+        if (wv::ballot(accepted)) {
+            double jp[NN][NPr];
+            calc_jp(jp);
+            sfor<0, NN>([&](auto ic) ACME_LAMBDA {
+                constexpr int i = decltype(ic)::value;
+                oipiv[i] = accepted ? ipiv[i] : oipiv[i];
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[i][decltype(jc)::value] = sel(accepted, jm[i][decltype(jc)::value], olu[i][decltype(jc)::value]); });
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[i][decltype(jc)::value] = sel(accepted, jp[i][decltype(jc)::value], ojp[i][decltype(jc)::value]); });
+                lz[i] = sel(accepted, z[i], lz[i]);
+            });
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA { lp[decltype(jc)::value] = sel(accepted, target[decltype(jc)::value], lp[decltype(jc)::value]); });
         }
         return conv || accepted;
     };
@@ -342,7 +361,10 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             double cpv[CACHE][NPr];                     // all the stored p's first: ONE wait for the LDS
             sfor<0, CACHE>([&](auto ec) ACME_LAMBDA {
                 constexpr int e = decltype(ec)::value;
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { cpv[e][decltype(jc)::value] = cpl[(decltype(jc)::value * CACHE + e) * LANE_BLOCK]; });
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    if constexpr (CREG) cpv[e][decltype(jc)::value] = cpr[decltype(jc)::value][e];
+                    else cpv[e][decltype(jc)::value] = cpl[(decltype(jc)::value * CACHE + e) * LANE_BLOCK];
+                });
             });
             sfor<0, CACHE>([&](auto ec) ACME_LAMBDA {    // nearest stored p, first one on ties
                 constexpr int e = decltype(ec)::value;
@@ -352,7 +374,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                     const double tt = cpv[e][j] - target[j];
                     d = fma(tt, tt, d);
                 });
-                const bool c = (int)(e < ccount) & (int)(d < best);    // (&&: a branch per entry)
+                const bool c = CREG ? d < best : (bool)((int)(e < ccount) & (int)(d < best));    // (&&: a branch per entry)
                 best = c ? d : best;
                 idx = c ? e : idx;
             });
@@ -361,7 +383,9 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 const int e = hit ? idx : 0;
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    const double v = cpl[(j * CACHE + e) * LANE_BLOCK];
+                    double v = 0.0;
+                    if constexpr (CREG) sfor<0, CACHE>([&](auto ec) ACME_LAMBDA { v = e == decltype(ec)::value ? cpr[j][decltype(ec)::value] : v; });
+                    else v = cpl[(j * CACHE + e) * LANE_BLOCK];
                     lp[j] = hit ? v : lp[j];
                 });
                 (void)cpv;
@@ -380,7 +404,11 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             const bool keep = need && c && its > 5;
             if (keep) {
                 const int slot = ccount < CACHE ? ccount : chead;
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { cpl[(decltype(jc)::value * CACHE + slot) * LANE_BLOCK] = target[decltype(jc)::value]; });
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (CREG) sfor<0, CACHE>([&](auto ec) ACME_LAMBDA { cpr[j][decltype(ec)::value] = slot == decltype(ec)::value ? target[j] : cpr[j][decltype(ec)::value]; });
+                    else cpl[(j * CACHE + slot) * LANE_BLOCK] = target[j];
+                });
                 sfor<0, NN>([&](auto ic) ACME_LAMBDA { cag[S::CACHE1 + slot * NN + decltype(ic)::value] = z[decltype(ic)::value]; });
                 chead = ccount < CACHE ? chead : (chead + 1) & (CACHE - 1);
                 ccount = ccount < CACHE ? ccount + 1 : ccount;
@@ -528,7 +556,11 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             meta[1] = chead;
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                for (int e = 0; e < CACHE; ++e) cag[j * CACHE + e] = cpl[(j * CACHE + e) * LANE_BLOCK];
+                if constexpr (CREG) {
+                    sfor<0, CACHE>([&](auto ec) ACME_LAMBDA { cag[j * CACHE + decltype(ec)::value] = decltype(ec)::value < ccount ? cpr[j][decltype(ec)::value] : 0.0; });
+                } else {
+                    for (int e = 0; e < CACHE; ++e) cag[j * CACHE + e] = cpl[(j * CACHE + e) * LANE_BLOCK];
+                }
             });
         }
         long long *rp = A.report + inst * RW_WORDS;
