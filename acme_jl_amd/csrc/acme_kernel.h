@@ -96,7 +96,19 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // extrapolation is one small mat-vec -- cheaper than recording and replaying the elimination
     // while np is small (measured on MI355X: replaying gains 9 % at np = 11 / nn = 13 and loses
     // 2 % at 5 / 7, 6 % at 3 / 4, 7 % at 1 / 2, where its nn dependent DPP steps dominate).
-    static constexpr bool MULT = NP >= 8;
+#ifndef ACME_MULT_NP       /* thresholds of the per-shape policies below (A/B builds) */
+#define ACME_MULT_NP 8
+#endif
+#ifndef ACME_FUSE_NP
+#define ACME_FUSE_NP 8
+#endif
+#ifndef ACME_GJHEAD_NP
+#define ACME_GJHEAD_NP 8
+#endif
+#ifndef ACME_SAFE0_NP
+#define ACME_SAFE0_NP 8
+#endif
+    static constexpr bool MULT = NP >= ACME_MULT_NP;
     // Three more choices follow the same split (A/B on MI355X, EXPERIMENTS.md): on the big shape,
     // whose two waves per SIMD compete for issue slots, fewer instructions win; on the small shapes,
     // whose launches last as long as ONE wave's dependent chains, shorter chains win.
@@ -107,7 +119,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     //   SAFE0   step 0 of the elimination with the two DPP wait states built into every fused
     //           operation (the compiler may copy a row register just before it; it does on the
     //           small shapes, never on the big one -- tools/dpp_hazard_check.py proves which):  big +1 % without
-    static constexpr bool FUSE = MULT, GJHEAD = MULT, SAFE0 = !MULT;
+    static constexpr bool FUSE = NP >= ACME_FUSE_NP, GJHEAD = NP >= ACME_GJHEAD_NP, SAFE0 = NP < ACME_SAFE0_NP;
     // solve(solver, p) (acme_batch_solve) as a kernel of its own (wave_main MODE_SOLVE), which takes its
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %, the big one -1.5 % (it keeps both in one)
     static constexpr bool SOLVE_SPLIT = !MULT;

@@ -66,3 +66,5 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     with open(out + "/pmc_traffic.json", "w") as fh:
         json.dump(rec, fh, indent=1)
 PY
+# the rocpd databases (tens of MB per pass) have served their purpose: gpurun merges at most 64 MiB back
+find "$OUT" -name "*.db" -delete
