@@ -45,7 +45,7 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         con = sqlite3.connect(f)
         print("== counters", grp)
         for r in con.execute("select counter_name, count(*), avg(value) from counters_collection "
-                             "where kernel_name like '%acme%' group by counter_name"):
+                             "where kernel_name like '%acme_run_kernel%' or kernel_name like '%acme_lane_kernel%' group by counter_name"):   # (not the one-off solve / Jacobian kernels)
             print("%-28s dispatches=%d per_dispatch=%.6g" % r)
             vals[r[0]] = r[2]
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
