@@ -80,7 +80,17 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // row constants staged in LDS: the kind-by-kind evaluation (RARE) reads all ROWC of them, the
     // unified rows only UR_SA .. UR_W1
     static constexpr int RC0 = RARE ? 0 : UR_SA;
-    static constexpr int ROWC_L = RARE ? ROWC : UR_W1 - UR_SA + 1;
+    // RCPAIR (big non-RARE shapes): the 13 constants of a unified row are staged in PAIRS (sA sB | cA cB |
+    // dA dB | h - | g0 g1 | g2 w0 | w1 -) and fetched by every evaluate! as 7 16-byte reads instead of
+    // living in 14 registers: those registers were re-assigned inside the Newton loop whenever the lanes
+    // adopt a new row order, and the compiler paid for that with 26 register copies per Newton pass
+    // (+2.1 % on the headline, 25 registers freed)
+#ifndef ACME_NO_RCPAIR
+    static constexpr bool RCPAIR = !RARE && L.pairs;
+#else
+    static constexpr bool RCPAIR = false;
+#endif
+    static constexpr int ROWC_L = RARE ? ROWC : RCPAIR ? 14 : UR_W1 - UR_SA + 1;
     static constexpr int ROWI_L = (ROWI + 1) / 2;            // doubles holding the ROWI ints of a row
     // persistent state per instance: x | last_p of every sub-problem | last_z of every sub-problem
     static constexpr int STATE = NX + NSUBr * (NP + NN);
@@ -389,6 +399,26 @@ ACME_DEV double rcv(const RowDesc &rd, int c) { return rd.rc[c * GROUP]; }
 // instructions whatever element its row belongs to; the kind-by-kind version below costs ~60
 // instructions in nested exec-masked regions.  xA/xB are the exponentials' arguments (0 for
 // rows without a junction: exp(0) - 1 = 0).
+// ... with the row's 13 constants handed over (c[i] = constant UR_SA + i)
+template <int NT>
+ACME_DEV void eval_row_unified_c(const double (&c)[14], const double (&e)[NT], double exA, double exB,
+                                 double &res, double (&tv)[NT]) {
+    const double cA = c[UR_CA - UR_SA], cB = c[UR_CB - UR_SA], dA = c[UR_DA - UR_SA], dB = c[UR_DB - UR_SA],
+                 h = c[UR_H - UR_SA];
+    const double g0 = c[UR_G0 - UR_SA], g1 = c[UR_G1 - UR_SA], g2 = c[UR_G2 - UR_SA], w0 = c[UR_W0 - UR_SA],
+                 w1 = c[UR_W1 - UR_SA];
+    const double hw = h * fma(w1, e[2], w0);
+    double r = cA * (exA - 1.0);
+    r = fma(cB, exB - 1.0, r);
+    r = fma(g0, e[0], r);
+    r = fma(g1, e[1], r);
+    r = fma(g2, e[2], r);
+    res = fma(hw, e[1], r);
+    tv[0] = fma(dA, exA, g0);
+    tv[1] = fma(dB, exB, g1 + hw);
+    tv[2] = fma(h, e[1], g2);
+    for (int t = 3; t < NT; ++t) tv[t] = 0.0;
+}
 template <int NT>
 ACME_DEV void eval_row_unified(const RowDesc &rd, const double (&e)[NT], double exA, double exB,
                                double &res, double (&tv)[NT]) {
@@ -610,8 +640,14 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             }
         }
         for (int s = 0; s < NSUB; ++s)     // only the constants this shape's row evaluation reads
-            for (int i = tid; i < S::ROWC_L * GROUP; i += nthreads)
-                lds_rowc[s * S::ROWC_L * GROUP + i] = A.rowc[(s * ROWC + S::RC0) * GROUP + i];
+            for (int i = tid; i < S::ROWC_L * GROUP; i += nthreads) {
+                if constexpr (S::RCPAIR) {      // i = ((pair * 16 + row) * 2 + half)
+                    const int c = (i / (2 * GROUP)) * 2 + (i & 1), row = (i >> 1) & (GROUP - 1);
+                    lds_rowc[s * S::ROWC_L * GROUP + i] = c < UR_W1 - UR_SA + 1 ? A.rowc[(s * ROWC + S::RC0 + c) * GROUP + row] : 0.0;
+                } else {
+                    lds_rowc[s * S::ROWC_L * GROUP + i] = A.rowc[(s * ROWC + S::RC0) * GROUP + i];
+                }
+            }
         for (int i = tid; i < NSUB * ROWI * GROUP; i += nthreads) lds_rowi[i] = A.rowi[i];
     }
     wv::block_sync();
@@ -647,11 +683,12 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         rd.kind = (lig < NN) ? rowi_s[0 * GROUP + rowid] : RK_NONE;
         rd.erow = rowi_s[1 * GROUP + rowid];
         rd.flags = rowi_s[2 * GROUP + rowid];
-        rd.rc = rowc_s + rowid;            // rc[c * GROUP] = row constant RC0 + c
+        rd.rc = rowc_s + (S::RCPAIR ? 2 : 1) * rowid;            // rc[c * GROUP] = row constant RC0 + c (RCPAIR: pair c at rc[c * 2 * GROUP])
         grow = (L.gs == GROUP || lig < NN) ? rowid : NN;
         // register-cached constants: the kind-by-kind evaluation (RARE shapes) wants rc[0..7],
         // the unified rows sA sB cA cB dA dB h
-        sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
+        if constexpr (!S::RCPAIR)
+            sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
         if constexpr (S::FQREG) {
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
@@ -821,14 +858,25 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             ACME_T2(TB_E2);
             eval_row<true, NT>(rd, e, exA, exB, res, tv);
         } else {
+            double urc[14];
+            if constexpr (S::RCPAIR) {
+                sfor<0, 7>([&](auto pc) ACME_LAMBDA {
+                    constexpr int p = decltype(pc)::value;
+                    const wv::pair_t v = wv::ld2(&rd.rc[p * 2 * GROUP]);
+                    urc[2 * p] = v.lo;
+                    urc[2 * p + 1] = v.hi;
+                });
+            }
+            const double sA = S::RCPAIR ? urc[0] : rd.k[0], sB = S::RCPAIR ? urc[1] : rd.k[1];
             if (has_bjt) {                                            // sA/sB = 0: exp(0) = 1
-                exp_junction2(e[0] * rd.k[0], e[1] * rd.k[1], exA, exB);
+                exp_junction2(e[0] * sA, e[1] * sB, exA, exB);
             } else {
-                exA = exp_junction(e[0] * rd.k[0]);
+                exA = exp_junction(e[0] * sA);
                 exB = 1.0;
             }
             ACME_T2(TB_E2);
-            eval_row_unified<NT>(rd, e, exA, exB, res, tv);
+            if constexpr (S::RCPAIR) eval_row_unified_c<NT>(urc, e, exA, exB, res, tv);
+            else eval_row_unified<NT>(rd, e, exA, exB, res, tv);
         }
         ACME_T2(TB_E3);
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
