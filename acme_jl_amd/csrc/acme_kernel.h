@@ -64,7 +64,10 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr bool LINREG = false;
 #endif
 #ifndef ACME_NO_DQREG
-    static constexpr bool DQREG = LINREG && NP > 0 && NLC + NX + NU <= 24;     // (fixed-pot superover: 20 + 12, spills)
+#ifndef ACME_DQREG_MAX
+#define ACME_DQREG_MAX 24
+#endif
+    static constexpr bool DQREG = LINREG && NP > 0 && NLC + NX + NU <= ACME_DQREG_MAX;     // (fixed-pot superover: 20 + 12, spills)
 #else
     static constexpr bool DQREG = false;
 #endif
@@ -80,13 +83,14 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // row constants staged in LDS: the kind-by-kind evaluation (RARE) reads all ROWC of them, the
     // unified rows only UR_SA .. UR_W1
     static constexpr int RC0 = RARE ? 0 : UR_SA;
-    // RCPAIR (big non-RARE shapes): the 13 constants of a unified row are staged in PAIRS (sA sB | cA cB |
+    // RCPAIR (the non-RARE shapes): the 13 constants of a unified row are staged in PAIRS (sA sB | cA cB |
     // dA dB | h - | g0 g1 | g2 w0 | w1 -) and fetched by every evaluate! as 7 16-byte reads instead of
     // living in 14 registers: those registers were re-assigned inside the Newton loop whenever the lanes
     // adopt a new row order, and the compiler paid for that with 26 register copies per Newton pass
-    // (+2.1 % on the headline, 25 registers freed)
+    // (+2.1 % on the headline with 25 registers freed, +2.1 % on config 4 -- whose 6 spills go --, +4.6 % on
+    // the birdie, +3.2 % on the 16-lane diode clipper)
 #ifndef ACME_NO_RCPAIR
-    static constexpr bool RCPAIR = !RARE && L.pairs;
+    static constexpr bool RCPAIR = !RARE;
 #else
     static constexpr bool RCPAIR = false;
 #endif
