@@ -284,6 +284,9 @@ template <int NN> struct RowLU {
                                                      double (&c)[NC > 0 ? NC : 1], double *slab, bool keep) {
         unsigned long long viol = 0;
         double dinv = 1.0;   // reciprocal of this lane's pivot
+        // STORE: the multipliers wait in registers and go to the slab in ONE predicated region at the end
+        // (a store per step costs an exec save / restore each -- and two v_readlane when the mask is spilled)
+        double rec[STORE ? NN : 1];
         unsigned long long pivlanes = rows4(1ull);   // lanes holding the pivot row of step k (lig == k)
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
@@ -307,7 +310,11 @@ template <int NN> struct RowLU {
             }
             const unsigned long long big = wv::ballot(fabs(nlm) > PIVOT_THRESHOLD);
             if constexpr (STORE) {
+#ifndef ACME_STORE_PER_STEP
+                rec[k] = nlm;
+#else
                 if (keep) slab[SH::oslot(k)] = nlm;
+#endif
             }
             // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
             viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
@@ -321,7 +328,12 @@ template <int NN> struct RowLU {
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
         if constexpr (STORE) {
-            if (keep) slab[SH::oslot(NN)] = dinv;
+            if (keep) {
+#ifndef ACME_STORE_PER_STEP
+                sfor<0, NN>([&](auto kc) ACME_LAMBDA { slab[SH::oslot(decltype(kc)::value)] = rec[decltype(kc)::value]; });
+#endif
+                slab[SH::oslot(NN)] = dinv;
+            }
         }
         // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
         viol |= wv::ballot(!(b * 0.0 == 0.0));
