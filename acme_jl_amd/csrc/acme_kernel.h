@@ -692,7 +692,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // hint and then follows the LU: whenever a factorisation has to interchange rows, the
     // lanes ADOPT the pivoted order, so the next factorisation finds its pivots in place.
     int rowid = lig;
-    int grow = lig;      // ... and its row in the row-gathered copies (lanes beyond NN: the all-zero row, Layout::gs)
+    int grow_ = lig;     // ... and its row in the row-gathered copies (lanes beyond NN: the all-zero row, Layout::gs;
+#define grow (*(L.gs == GROUP ? &rowid : &grow_))      /* the same number when the copies have 16 rows */
     RowDesc rd;
     double fqreg[S::FQREG ? NT : 1][S::FQREG ? NNr : 1];
     auto load_rowdesc = [&]() ACME_LAMBDA {
@@ -700,7 +701,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         rd.erow = rowi_s[1 * GROUP + rowid];
         rd.flags = rowi_s[2 * GROUP + rowid];
         rd.rc = rowc_s + (S::RCPAIR ? 2 : 1) * rowid;            // rc[c * GROUP] = row constant RC0 + c (RCPAIR: pair c at rc[c * 2 * GROUP])
-        grow = (L.gs == GROUP || lig < NN) ? rowid : NN;
+        if constexpr (L.gs != GROUP) grow = lig < NN ? rowid : NN;
         // register-cached constants: the kind-by-kind evaluation (RARE shapes) wants rc[0..7],
         // the unified rows sA sB cA cB dA dB h
         if constexpr (!S::RCPAIR)
@@ -729,7 +730,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     double pf[NT];       // (q0 + pexp*p) at the q rows rd.tc[] of this lane's residual row
     // per-row results of the latest evaluate!
     double a[NNr];       // J row -> LU row
-    int orig = lig;
     double res = 0.0;
     double tv[NT];
 
@@ -950,7 +950,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
 
     // After a pivoted factorisation the lane at position i holds what was row orig[i]: make
     // that the lane's row from now on (row descriptor and the latest Jq non-zeros move along).
-    auto adopt = [&]() ACME_LAMBDA {
+    auto adopt = [&](int orig) ACME_LAMBDA {
         rowid = wv::shfl16(rowid, orig);
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
@@ -987,10 +987,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             if (phase == 1) {
                 // only the instances that tripped the threshold change their row order: what an
                 // instance computes must not depend on which other instances share its wave
+                int orig;        // (local: nothing of it lives across the loops)
                 const bool okp = LU::pivot_order(a, orig, lig, grp);
                 ok = relearn ? okp : true;
                 orig = relearn ? orig : lig;
-                adopt();
+                adopt(orig);
                 if constexpr (S::MULT) stale = stale || relearn;   // the recorded elimination is per row order
                 phase = 2;
                 ACME_T(TB_PIVOT);
@@ -1229,9 +1230,10 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 phase = wv::opaque(phase);
                 (void)evaluate(lz);
                 if (phase == 1) {
+                    int orig;
                     (void)LU::pivot_order(a, orig, lig, grp);
                     orig = relearn ? orig : lig;
-                    adopt();
+                    adopt(orig);
                     phase = 2;
                     continue;
                 }
@@ -1598,5 +1600,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
     }
 }
+#undef grow
 
 }  // namespace acme
