@@ -137,6 +137,14 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // solve(solver, p) (acme_batch_solve) as a kernel of its own (wave_main MODE_SOLVE), which takes its
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %, the big one -1.5 % (it keeps both in one)
     static constexpr bool SOLVE_SPLIT = !MULT;
+    // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
+    // them since their row constants went to LDS): no scalar loads per evaluate!, and 32 of the 102 scalar
+    // registers back -- headline +1.5 %, config 4 +2.0 % (with 8 spilled registers), birdie +3.3 %
+#ifndef ACME_NO_EXPV
+    static constexpr bool EXPV = !RARE;
+#else
+    static constexpr bool EXPV = false;
+#endif
     // the row-gathered fq entries of this lane's residual row (NT x NN doubles, used twice per
     // evaluate!) stay in registers between the rare changes of the lane's row instead of being
     // re-read from LDS by every evaluate!: since the extrapolation origin moved to the recorded
@@ -239,6 +247,42 @@ ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb, const 
     pb = fma(pb, rb, 1.0);
     ea = ldexp(pa, (int)wv::clamp_s(ka, t[14], t[15]));
     eb = ldexp(pb, (int)wv::clamp_s(kb, t[14], t[15]));
+}
+// ... on a table that lives in VECTOR registers for the whole kernel (the same value in every lane):
+// no scalar loads per call and none of the 32 scalar registers the table otherwise occupies
+struct ExpTabV { double v[16]; };
+ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb, const ExpTabV &T) {
+    const double *t = T.v;
+    const double ka = rint(xa * t[0]), kb = rint(xb * t[0]);
+    double ra = fma(-ka, t[1], xa), rb = fma(-kb, t[1], xb);
+    ra = fma(-ka, t[2], ra);
+    rb = fma(-kb, t[2], rb);
+    double pa = fma(ra, t[3], t[4]), pb = fma(rb, t[3], t[4]);
+    sfor<5, 14>([&](auto ic) ACME_LAMBDA {
+        constexpr int i = decltype(ic)::value;
+        pa = fma(pa, ra, t[i]);
+        pb = fma(pb, rb, t[i]);
+    });
+    pa = fma(pa, ra, 0.5);
+    pb = fma(pb, rb, 0.5);
+    pa = fma(pa, ra, 1.0);
+    pb = fma(pb, rb, 1.0);
+    pa = fma(pa, ra, 1.0);
+    pb = fma(pb, rb, 1.0);
+    ea = ldexp(pa, (int)fmin(fmax(ka, t[14]), t[15]));
+    eb = ldexp(pb, (int)fmin(fmax(kb, t[14]), t[15]));
+}
+ACME_DEV double exp_junction(double x, const ExpTabV &T) {
+    const double *t = T.v;
+    const double k = rint(x * t[0]);
+    double r = fma(-k, t[1], x);
+    r = fma(-k, t[2], r);
+    double p = fma(r, t[3], t[4]);
+    sfor<5, 14>([&](auto ic) ACME_LAMBDA { p = fma(p, r, t[decltype(ic)::value]); });
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)fmin(fmax(k, t[14]), t[15]));
 }
 // ... with the 16 constants fetched on the spot (two scalar loads per call)
 ACME_DEV double exp_junction(double x) { return exp_junction(x, wv::load_exp_tab()); }
@@ -718,6 +762,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     };
     load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
+    ExpTabV etv;
+    if constexpr (S::EXPV) {
+        const wv::ExpTab t0 = wv::load_exp_tab();
+        sfor<0, 16>([&](auto ic) ACME_LAMBDA { etv.v[decltype(ic)::value] = wv::keep(t0[decltype(ic)::value]); });
+    }
 
     // ---- persistent per-instance state, in registers for the whole launch --------------
     double x[NXSr];      // state vector, element s*16+lig
@@ -885,9 +934,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             }
             const double sA = S::RCPAIR ? urc[0] : rd.k[0], sB = S::RCPAIR ? urc[1] : rd.k[1];
             if (has_bjt) {                                            // sA/sB = 0: exp(0) = 1
-                exp_junction2(e[0] * sA, e[1] * sB, exA, exB);
+                if constexpr (S::EXPV) exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
+                else exp_junction2(e[0] * sA, e[1] * sB, exA, exB);
             } else {
-                exA = exp_junction(e[0] * sA);
+                if constexpr (S::EXPV) exA = exp_junction(e[0] * sA, etv);
+                else exA = exp_junction(e[0] * sA);
                 exB = 1.0;
             }
             ACME_T2(TB_E2);
