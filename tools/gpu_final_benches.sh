@@ -16,4 +16,4 @@ ACME_LANE_KERNEL=0 run diodeclipper_sweep_16lane --workload diodeclipper_sweep -
 run birdie_grid --workload birdie_grid --steps 3 --warmup 1
 run montecarlo_T44100 --workload superover_montecarlo --steps 3 --warmup 2
 run full_homotopy --solver homotopy --steps 3 --warmup 2
-run full_gather_rccl1 --steps 2 --warmup 1
+run full_gather_rccl1 --gather rank0 --steps 2 --warmup 1
