@@ -1162,6 +1162,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             });
         }
         z = sel(need, lz - t, z);
+#ifdef ACME_FLAGS_MASK     /* the flags as lane masks (before: birdie -1.8 %, config 4 -0.4 %, headline +-0) */
         bool act = need, conv = false, accepted = false;
         its = 0;
         ACME_T(TB_SETUP);
@@ -1186,6 +1187,35 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         lz = sel(accepted, z, lz);
         lp = sel(accepted, target, lp);
         return conv || accepted;
+#else
+        // the loop-carried per-lane flags as integers in vector registers (bit 0 act, 1 conv, 2 accepted):
+        // as 64-bit lane masks they were spilled and re-read through v_writelane / v_readlane every pass
+        int fl = wv::keepi(need ? 1 : 0);
+        its = 0;
+        ACME_T(TB_SETUP);
+        while (wv::ballot((fl & 1) != 0)) {
+            const bool act = (fl & 1) != 0;
+            its += fl & 1;
+            bool finite, ok, small;
+            double dz;
+            linearize(z, act, false, finite, ok, small, dz);
+            const bool want = act && finite && ok && small;
+            const bool stop_bad = act && (!finite || !ok);
+            const bool step = act && !stop_bad && !want;
+            z = sel(step, z - dz, z);
+            int nf = fl & ~1;
+            nf = (stop_bad && !(finite && small)) ? (nf & ~2) : nf;
+            nf = (stop_bad && finite && small) ? (nf | 2) : nf;
+            nf = want ? (nf | 4) : nf;
+            nf = (step && its < A.maxiter) ? (nf | 1) : nf;
+            fl = wv::keepi(nf);
+            ACME_T(TB_GLUE);
+        }
+        const bool accepted = (fl & 4) != 0;
+        lz = sel(accepted, z, lz);
+        lp = sel(accepted, target, lp);
+        return (fl & 6) != 0;
+#endif
     };
 
     // solve(::CachingSolver, p) (src/solvers.jl:347-396) around the base solve, with a bounded
