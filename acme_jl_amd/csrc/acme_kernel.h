@@ -1465,6 +1465,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 if (solve_mode) p = (valid && lig < A.np_io) ? A.p_in[inst * A.np_io + lig] : 0.0;
                 // solve(::HomotopySolver, p) (src/solvers.jl:268-296) as a per-instance
                 // state machine; every base solve is shared by the wave
+#ifdef ACME_HFLAGS_MASK
                 bool need = alive, conv = false;
                 int mode = 0, its_sample = 0;
                 double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
@@ -1502,6 +1503,45 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                     }
                     ACME_T(TB_HOMO);
                 }
+#else
+                // (need / hasconverged as bits 0 / 1 of an integer in a vector register: see base_solve)
+                int hf = wv::keepi(alive ? 1 : 0);
+                int mode = 0, its_sample = 0;
+                double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
+                ACME_DBG("sample %lld sub %d lane %d p %.17g x %.17g lp %.17g lz %.17g", n, s, lane, p, x[0], lp, lz);
+                ACME_T(TB_PRE);
+                while (wv::ballot((hf & 1) != 0)) {
+                    bool need = (hf & 1) != 0;
+                    int its;
+                    bool c = cached_solve(target, need, its);
+                    its_sample += need ? its : 0;
+                    int nh = need ? ((hf & ~2) | (c ? 2 : 0)) : hf;
+                    if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c))) {
+                        nh &= ~1;
+                    } else {
+                        bool direct = need && mode == 0;
+                        bool homot = need && mode == 1;
+                        bool start = direct && !c;
+                        startp = sel(start, lp, startp);
+                        bool hgood = homot && c;
+                        hbest = sel(hgood, ha, hbest);
+                        double new_a = (ha + hbest) / 2.0;
+                        bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
+                        ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
+                        ha = sel(start, 0.5, ha);
+                        hbest = sel(start, 0.0, hbest);
+                        mode = sel(start, 1, mode);
+                        need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
+                        double pa = startp * (1.0 - ha);
+                        pa = pa + ha * p;
+                        target = sel(need, pa, target);
+                        nh = need ? (nh | 1) : (nh & ~1);
+                    }
+                    hf = wv::keepi(nh);
+                    ACME_T(TB_HOMO);
+                }
+                const bool conv = (hf & 2) != 0;
+#endif
                 zs[s] = alive ? z : 0.0;
                 if (solve_mode) {   // hand the solver's answer back; no y, no state update
                     if (valid && lig < A.nn_io) A.z_out[inst * A.nn_io + lig] = z;
