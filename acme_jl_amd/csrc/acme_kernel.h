@@ -793,13 +793,13 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // the sub-problem being solved
     double lps[NSUB], lzs[NSUB], zs[NSUB];
     int rowids[NSUB];
-    bool stales[NSUB];
+    int stales[NSUB];
     sfor<0, NSUB>([&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         lps[s] = (NP > 0 && valid && lig < NP) ? st[NX + s * NP + lig] : 0.0;
         lzs[s] = (NN > 0 && valid && lig < NN) ? st[NX + NSUB * NP + s * NN + lig] : 0.0;
         zs[s] = 0.0;
-        stales[s] = true;
+        stales[s] = 1;
         rowids[s] = valid ? A.roworder[(inst * NSUB + s) * GROUP + lig] : lig;
     });
     const int nsub = (NN > 0) ? A.nsub : 0;
@@ -1028,7 +1028,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // `stale`: the slab no longer describes the origin (lp, lz) in the lanes' current order -- an
     // instance changed its row order without storing a new origin, or a recorded elimination was
     // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
-    bool stale = true;
+    int stale = 1;       // (an integer in a vector register, like the loop flags of base_solve)
     auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
         ok = true;
         int phase = 0;   // 0: first try   1: learn the pivot order   2: retry in the new order
@@ -1045,7 +1045,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 ok = relearn ? okp : true;
                 orig = relearn ? orig : lig;
                 adopt(orig);
-                if constexpr (S::MULT) stale = stale || relearn;   // the recorded elimination is per row order
+                if constexpr (S::MULT) stale = relearn ? 1 : stale;   // the recorded elimination is per row order
                 phase = 2;
                 ACME_T(TB_PIVOT);
                 continue;
@@ -1094,8 +1094,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 }
                 // MULT: recorded and kept -> the slab is the origin-to-be; recorded but unusable -> it
                 // is nothing.  Otherwise the slab is only written when the result is kept.
-                if constexpr (S::MULT) stale = want ? mine : stale;
-                else stale = stale && !(want && !mine);
+                if constexpr (S::MULT) stale = want ? (mine ? 1 : 0) : stale;
+                else stale = (want && !mine) ? 0 : stale;
             }
             ACME_T(TB_STORE);
             break;
@@ -1231,7 +1231,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     auto cached_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
         double *cp = cch, *cz = czg;
         int *meta = reinterpret_cast<int *>(cch + NP * CACHE);   // count, head
-        bool reorig = stale;        // (lp, lz) not linearised (in this row order): launch start, ..., or new origin below
+        bool reorig = stale != 0;   // (lp, lz) not linearised (in this row order): launch start, ..., or new origin below
         if (caching) {
             const int count = meta[0];
             const double dl = (lig < NP) ? target - lp : 0.0;
