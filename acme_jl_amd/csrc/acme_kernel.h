@@ -1030,9 +1030,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
     int stale = 1;       // (an integer in a vector register, like the loop flags of base_solve)
     auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
-        ok = true;
+        int okf = 1;     // `ok`, and below `relearn`: carried across the phases as integers in vector registers
         int phase = 0;   // 0: first try   1: learn the pivot order   2: retry in the new order
-        bool relearn = false;   // this instance tripped the threshold in phase 0
+        int relearn_i = 0;      // this instance tripped the threshold in phase 0
         for (;;) {
             phase = wv::opaque(phase);
             finite = evaluate(zz);
@@ -1041,8 +1041,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 // only the instances that tripped the threshold change their row order: what an
                 // instance computes must not depend on which other instances share its wave
                 int orig;        // (local: nothing of it lives across the loops)
+                const bool relearn = relearn_i != 0;
                 const bool okp = LU::pivot_order(a, orig, lig, grp);
-                ok = relearn ? okp : true;
+                okf = relearn ? (okp ? 1 : 0) : 1;
                 orig = relearn ? orig : lig;
                 adopt(orig);
                 if constexpr (S::MULT) stale = relearn ? 1 : stale;   // the recorded elimination is per row order
@@ -1075,11 +1076,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             viol &= wv::ballot(act || force);   // the other instances' results are not used
             const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
             if (viol != 0ull && phase == 0) {
-                relearn = mine;
+                relearn_i = mine ? 1 : 0;
                 phase = 1;
                 continue;
             }
-            ok = ok && !mine;
+            okf = mine ? 0 : okf;
             if (recording) {
                 if (want && !mine && lig < NN) {   // per-lane predicated LDS stores
                     if constexpr (S::MULT) {
@@ -1100,6 +1101,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             ACME_T(TB_STORE);
             break;
         }
+        ok = okf != 0;
     };
 
     // switch the live solver context to sub-problem s / save it back
@@ -1344,11 +1346,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // kept in LDS (one copy per instance, updated by the instance's lane 0 once per sample)
     // rather than in registers of all 16 lanes: they are never needed inside the solver loop
     long long *rbuf = reinterpret_cast<long long *>(ybuf + S::YBUF);
-    bool dead = !valid;  // dead: the reference would have thrown at first_nonfinite
+    int dead = valid ? 0 : 1;  // dead: the reference would have thrown at first_nonfinite (an integer, like `stale`)
     if (valid) {
         const long long *rp = A.report + inst * RW_WORDS;
         if (lig < RW_WORDS) rbuf[lig] = rp[lig];
-        dead = rp[RW_FIRST_NONFINITE] >= 0;
+        dead = rp[RW_FIRST_NONFINITE] >= 0 ? 1 : 0;
     }
     wv::wave_fence();
 
@@ -1425,7 +1427,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 if (!(NN > 0 && s < nsub)) return;
                 if (solve_mode && s != A.solve_sub) return;
                 if (S::NSUB > 1) enter_sub(sc);
-                const bool alive = !dead;
+                const bool alive = dead == 0;
                 // p = dq*x + eq*u + fqprev*z  (src/ACME.jl:678-686)
                 double p = 0.0;
                 double dqe[NX + NU + 1];       // row lig of [dq | eq], two columns per LDS read where stored in pairs
@@ -1562,7 +1564,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                             if (rbuf[RW_FIRST_NONCONV] < 0) rbuf[RW_FIRST_NONCONV] = n;
                         }
                         if (lig == 0 && die && rbuf[RW_FIRST_NONFINITE] < 0) rbuf[RW_FIRST_NONFINITE] = n;
-                        dead = dead || die;
+                        dead = die ? 1 : dead;
                     }
                     if (lig == 0 && alive) {   // fire-and-forget LDS atomics: no round trip to wait for
                         wv::lds_add(&rbuf[RW_ITERS_TOTAL], (long long)its_sample);
@@ -1573,7 +1575,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             });
             if (solve_mode) continue;
             const bool refill = NU > 0 && m == cnt - 1 && n0 + S::CH < T;
-            const bool live = !dead;
+            const bool live = dead == 0;
             wv::sched_fence();
             constexpr int LD = NX + NY;
             if constexpr (NX + NY <= GROUP && NX > 0) {
