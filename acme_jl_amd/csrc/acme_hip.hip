@@ -51,6 +51,17 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
     lane_main<S>(A, acme_lds);
 }
 
+// LDS budgets the performance of the BASELINE workloads rests on (a CU has 160 KB: two blocks -- two waves per
+// SIMD -- need 80 KB each, solution caches included)
+#ifndef ACME_DEV_SHAPES
+static_assert(sizeof(double) * (Shape<13, 29, 11, 11, 4, 1, 0, 1>::lds_doubles(false) +
+                                INST_PER_BLOCK * Shape<13, 29, 11, 11, 4, 1, 0, 1>::CACHEI) <= 80 * 1024,
+              "headline shape: two blocks per CU");
+static_assert(sizeof(double) * (Shape<7, 14, 5, 11, 1, 1, 0, 1>::lds_doubles(true) +
+                                INST_PER_BLOCK * Shape<7, 14, 5, 11, 1, 1, 0, 1>::CACHEI) <= 80 * 1024,
+              "fixed-pot superover with 16 private images per block (BASELINE config 4): two blocks per CU, one round");
+#endif
+
 struct KernelEntry {
     Dims d;
     const void *fn, *fn_jac, *fn_solve, *fn_lane;
