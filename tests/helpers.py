@@ -119,3 +119,22 @@ def analytic_cases():
     c, _ = circuits.resistor_diode_circuit()
     cases.append(("resistor_diode", DiscreteModel(c, one), np.zeros((1, 0, 3))))
     return cases
+
+
+def rare_per_instance_case(n=4):
+    """(models, u): n Jiles-Atherton inductor circuits (a RARE, kind-by-kind shape with states) whose linear
+    inductor differs from instance to instance, and a step input per instance: private model images in a
+    shape whose lanes keep their rows of the linear update in registers."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.circuit import inductor
+    from acme_jl_amd.model import DiscreteModel
+    models = []
+    for k in range(n):
+        c = circuits.ja_inductor_circuit()
+        c.elements["L_lin"] = inductor(174e-3 * (1 + 0.1 * (k - 1.5)))
+        models.append(DiscreteModel(c, Fraction(1, 44100)))
+    u1 = np.concatenate([np.full(150, 0.1), np.full(150, -0.1), np.zeros(40)])
+    u = np.stack([u1 * (1 + 0.2 * k) for k in range(n)])[:, None, :]
+    return models, u
+

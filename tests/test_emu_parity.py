@@ -103,6 +103,19 @@ def test_emulated_per_instance_matrices(emu_lib):
     assert np.abs(y[0] - y[4]).max() > 1e-4   # the instances really differ
 
 
+def test_emulated_per_instance_matrices_rare_shape(emu_lib):
+    """Private model images in a RARE (kind-by-kind) shape with states: the lanes keep their rows of the
+    linear update in registers (Shape::LINREG) and a block stages only the solver's part of each image."""
+    from helpers import rare_per_instance_case
+    from acme_jl_amd.runner import ModelRunner
+    models, u = rare_per_instance_case()
+    y = ModelRunner(models[0], len(models), models=models, lib=emu_lib).run(u)
+    for k in range(len(models)):
+        yref, _ = oracle_run(models[k], u[k:k + 1])
+        assert_close(y[k:k + 1], yref)
+    assert np.abs(y[0] - y[3]).max() > 1e-6   # the instances really differ
+
+
 def test_emulated_monte_carlo_superover(emu_lib):
     """BASELINE config 4 in miniature (component tolerances on the fixed-pot superover): every
     instance must start from ITS model's initial solution, not the batch model's."""

@@ -241,6 +241,18 @@ def test_full_size_superover_grid(hip_lib):
     assert (ra["n_warn"] == 0).all()
 
 
+def test_per_instance_matrices_rare_shape(hip_lib):
+    """Private model images in a RARE shape with states (Jiles-Atherton inductor, linear inductor varied per
+    instance): register-resident rows of the linear update + partially staged images, against the oracle."""
+    from helpers import rare_per_instance_case
+    from acme_jl_amd.runner import ModelRunner
+    models, u = rare_per_instance_case(21)
+    y = ModelRunner(models[0], len(models), models=models, lib=hip_lib).run(u)
+    for k in (0, 7, 16, 20):
+        yref, _ = oracle_run(models[k], u[k:k + 1])
+        assert_close(y[k:k + 1], yref)
+
+
 def test_monte_carlo_per_instance_superover(hip_lib):
     """BASELINE config 4 in miniature: fixed-pot superover with every resistor, capacitor and pot
     track scaled by 1 + 0.05*U(-1,1) (PCG64 seed 20250905), one private model block per instance.
