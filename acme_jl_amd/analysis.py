@@ -98,7 +98,7 @@ def steadystate_(runner, u=None):
     return X
 
 
-def linearize(model, usteady=None, lib=None, device=None, reference_offsets=False):
+def linearize(model, usteady=None, lib=None, device=None, reference_offsets=True):
     """``linearize(model, usteady)`` (src/ACME.jl:505-550, src/solvers.jl:407-414): the small-signal
     linear ``DiscreteModel`` around the steady state for the constant input ``usteady``.
 
@@ -109,13 +109,14 @@ def linearize(model, usteady=None, lib=None, device=None, reference_offsets=Fals
 
     Models with several nonlinear sub-problems: the small-signal gains (a, b, dy, ey) follow the
     reference's recursion (dqlins / eqlins, :530-532).  For the constant terms (x0, y0) the
-    reference adds c (z_k - dzdp_k p_k) per sub-problem (:534,538), which leaves out what the
-    affine offsets of the EARLIER sub-problems contribute to p_k through fqprev: with that formula
-    the linear model of a decomposed circuit does not reproduce the operating point it was
-    linearised at (0.05 V off on tests/circuits.two_stage_clipper; the reference's own tests only
-    linearise single-sub-problem models).  The default here carries the offsets through, which
-    makes decomposed and non-decomposed derivations of one circuit agree to rounding;
-    ``reference_offsets=True`` reproduces the reference's formula literally."""
+    reference adds c (z_k - dzdp_k p_k) per sub-problem (:534,538) -- the DEFAULT here
+    (``reference_offsets=True``: upstream results are reproduced literally).  That formula leaves out
+    what the affine offsets of the EARLIER sub-problems contribute to p_k through fqprev: the linear
+    model of a decomposed circuit then does not reproduce the operating point it was linearised at
+    (0.05 V off on tests/circuits.two_stage_clipper; the reference's own tests only linearise
+    single-sub-problem models, where the two forms coincide).  ``reference_offsets=False`` carries the
+    offsets through, which makes decomposed and non-decomposed derivations of one circuit agree to
+    rounding."""
     u = np.zeros(model.nu) if usteady is None else np.asarray(usteady, dtype=np.float64)
     xs = steadystate(model, u, lib=lib, device=device)
     x0, a, b = model.x0.copy(), model.a.copy(), model.b.copy()
@@ -131,7 +132,14 @@ def linearize(model, usteady=None, lib=None, device=None, reference_offsets=Fals
             if not conv.all():
                 raise ValueError(f"Cannot linearize because no solution found at p={ps}")
             z = z[0]
-            dzdp = r.get_extrapolation_jacobian(sub=idx)[0]        # -(J \ Jp) at (ps, z): the solve made it the origin
+            # set_extrapolation_origin(solver, p, z) (src/solvers.jl:409): explicit, as in the reference -- a
+            # solve that reported convergence through the singular-J / small-residual exit has NOT moved it
+            _, p_all, z_all = r.get_state()
+            po = sum(t.np for t in model.subs[:idx])
+            p_all[0, po:po + s.np] = ps
+            z_all[0, zoff:zoff + s.nn] = z
+            r.set_state(p=p_all, z=z_all)
+            dzdp = r.get_extrapolation_jacobian(sub=idx)[0]        # -(J \ Jp) at (ps, z)
             if not np.isfinite(dzdp).all():
                 raise ValueError(f"Cannot linearize: singular Jacobian at p={ps}")
             zr = slice(zoff, zoff + s.nn)

@@ -58,19 +58,8 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // fixed-pot superover image is 2.7 KB instead of 7.6, two blocks fit a CU and the 8 192 instances
     // of BASELINE config 4 run in ONE round at two waves per SIMD.
     static constexpr int NLC = 1 + NX + NU + NSUBr * NN;
-#ifndef ACME_NO_LINREG
     static constexpr bool LINREG = NX > 0 && NX + NY <= GROUP && !L.linp && NSUB == 1 && NLC <= 20;
-#else
-    static constexpr bool LINREG = false;
-#endif
-#ifndef ACME_NO_DQREG
-#ifndef ACME_DQREG_MAX
-#define ACME_DQREG_MAX 24
-#endif
-    static constexpr bool DQREG = LINREG && NP > 0 && NLC + NX + NU <= ACME_DQREG_MAX;     // (fixed-pot superover: 20 + 12, spills)
-#else
-    static constexpr bool DQREG = false;
-#endif
+    static constexpr bool DQREG = LINREG && NP > 0 && NLC + NX + NU <= 24;     // (fixed-pot superover: 20 + 12, spills)
     // what a block stages of a PRIVATE image: [IMG0, IMG0 + IMGN) (a shared image is staged whole)
     static constexpr int IMG0 = LINREG ? L.sub0 + (DQREG ? L.pexpr : 0) : 0;
     static constexpr int IMGN = L.total - IMG0;
@@ -89,12 +78,8 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // adopt a new row order, and the compiler paid for that with 26 register copies per Newton pass
     // (+2.1 % on the headline with 25 registers freed, +2.1 % on config 4 -- whose 6 spills go --, +4.6 % on
     // the birdie, +3.2 % on the 16-lane diode clipper)
-#ifndef ACME_NO_RCPAIR
     static constexpr bool RCPAIR = !RARE;
-#else
-    static constexpr bool RCPAIR = false;
-#endif
-    static constexpr int ROWC_L = RARE ? ROWC : RCPAIR ? 14 : UR_W1 - UR_SA + 1;
+    static constexpr int ROWC_L = RARE ? ROWC : 14;
     static constexpr int ROWI_L = (ROWI + 1) / 2;            // doubles holding the ROWI ints of a row
     // persistent state per instance: x | last_p of every sub-problem | last_z of every sub-problem
     static constexpr int STATE = NX + NSUBr * (NP + NN);
@@ -110,19 +95,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // extrapolation is one small mat-vec -- cheaper than recording and replaying the elimination
     // while np is small (measured on MI355X: replaying gains 9 % at np = 11 / nn = 13 and loses
     // 2 % at 5 / 7, 6 % at 3 / 4, 7 % at 1 / 2, where its nn dependent DPP steps dominate).
-#ifndef ACME_MULT_NP       /* thresholds of the per-shape policies below (A/B builds) */
-#define ACME_MULT_NP 8
-#endif
-#ifndef ACME_FUSE_NP
-#define ACME_FUSE_NP 8
-#endif
-#ifndef ACME_GJHEAD_NP
-#define ACME_GJHEAD_NP 8
-#endif
-#ifndef ACME_SAFE0_NP
-#define ACME_SAFE0_NP 8
-#endif
-    static constexpr bool MULT = NP >= ACME_MULT_NP;
+    static constexpr bool MULT = NP >= 8;
     // Three more choices follow the same split (A/B on MI355X, EXPERIMENTS.md): on the big shape,
     // whose two waves per SIMD compete for issue slots, fewer instructions win; on the small shapes,
     // whose launches last as long as ONE wave's dependent chains, shorter chains win.
@@ -133,7 +106,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     //   SAFE0   step 0 of the elimination with the two DPP wait states built into every fused
     //           operation (the compiler may copy a row register just before it; it does on the
     //           small shapes, never on the big one -- tools/dpp_hazard_check.py proves which):  big +1 % without
-    static constexpr bool FUSE = NP >= ACME_FUSE_NP, GJHEAD = NP >= ACME_GJHEAD_NP, SAFE0 = NP < ACME_SAFE0_NP;
+    static constexpr bool FUSE = MULT, GJHEAD = MULT, SAFE0 = !MULT;
     // solve(solver, p) (acme_batch_solve) as a kernel of its own (wave_main MODE_SOLVE), which takes its
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %, the big one -1.5 % (it keeps both in one)
     static constexpr bool SOLVE_SPLIT = !MULT;
@@ -142,22 +115,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
     // them since their row constants went to LDS): no scalar loads per evaluate!, and 32 of the 102 scalar
     // registers back -- headline +1.5 %, config 4 +2.0 % (with 8 spilled registers), birdie +3.3 %
-#ifndef ACME_NO_EXPV
     static constexpr bool EXPV = !RARE;
-#else
-    static constexpr bool EXPV = false;
-#endif
-    // the row-gathered fq entries of this lane's residual row (NT x NN doubles, used twice per
-    // evaluate!) stay in registers between the rare changes of the lane's row instead of being
-    // re-read from LDS by every evaluate!: since the extrapolation origin moved to the recorded
-    // elimination the headline shape has the registers for it (2 x 39 of 256, no spills)
-#ifdef ACME_FQREG      /* experiment on the big shape: the register allocator answers with 371 spills (EXPERIMENTS.md) */
-    static constexpr bool FQREG = RARE_ == 0 && NSUB_ == 1 && NN_ * 3 <= 40;
-#elif defined(ACME_FQREG_SMALL)   /* ... and on the smallest ones: 63 spills on the birdie (232 registers without) */
-    static constexpr bool FQREG = RARE_ == 0 && NSUB_ == 1 && NN_ <= 4 && NN_ > 0;
-#else
-    static constexpr bool FQREG = false;
-#endif
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
     static constexpr int OS_MUL = 0, OS_DINV = NN, OS_TV = NN + 1, OS_PF = NN + 1 + NT;
     static constexpr int OSLOTS = MULT ? (NN + 1 + 2 * NT + 1) & ~1 : NP;
@@ -297,7 +255,6 @@ ACME_DEV double exp_junction(double x, const ExpTabV &T) {
 }
 // ... with the 16 constants fetched on the spot (two scalar loads per call)
 ACME_DEV double exp_junction(double x) { return exp_junction(x, wv::load_exp_tab()); }
-ACME_DEV void exp_junction2(double xa, double xb, double &ea, double &eb) { exp_junction2(xa, xb, ea, eb, wv::load_exp_tab()); }
 ACME_DEV int sel(bool c, int a, int b) { return c ? a : b; }
 
 // ---------------------------------------------------------------------------------------
@@ -312,10 +269,7 @@ template <int NN> struct RowLU {
     // equal size had swapped ranks: +10 % run time for differences at rounding level; 4 -> 8 buys
     // another 4.5 % (16 nothing more), with outputs equal to 12 digits and identical iteration
     // counts on every parity case (tests/solver_pins.py sweeps matrices built to separate the rules).
-#ifndef ACME_PIVOT_THRESHOLD
-#define ACME_PIVOT_THRESHOLD 8.0
-#endif
-        static constexpr double PIVOT_THRESHOLD = ACME_PIVOT_THRESHOLD;
+    static constexpr double PIVOT_THRESHOLD = 8.0;
 
     // Gauss-Jordan elimination of [A | b | C] in the CURRENT row order, without looking for
     // pivots -- valid whenever the rows already sit in (threshold-)pivot order, which is the
@@ -365,11 +319,7 @@ template <int NN> struct RowLU {
             }
             const unsigned long long big = wv::ballot(fabs(nlm) > PIVOT_THRESHOLD);
             if constexpr (STORE) {
-#ifndef ACME_STORE_PER_STEP
                 rec[k] = nlm;
-#else
-                if (keep) slab[SH::oslot(k)] = nlm;
-#endif
             }
             // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
             viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
@@ -384,9 +334,7 @@ template <int NN> struct RowLU {
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
         if constexpr (STORE) {
             if (keep) {
-#ifndef ACME_STORE_PER_STEP
                 sfor<0, NN>([&](auto kc) ACME_LAMBDA { slab[SH::oslot(decltype(kc)::value)] = rec[decltype(kc)::value]; });
-#endif
                 slab[SH::oslot(NN)] = dinv;
             }
         }
@@ -490,30 +438,6 @@ ACME_DEV void eval_row_unified_c(const double (&c)[14], const double (&e)[NT], d
     tv[2] = fma(h, e[1], g2);
     for (int t = 3; t < NT; ++t) tv[t] = 0.0;
 }
-template <int NT>
-ACME_DEV void eval_row_unified(const RowDesc &rd, const double (&e)[NT], double exA, double exB,
-                               double &res, double (&tv)[NT]) {
-    static_assert(NT >= 3, "unified rows use three q entries");
-    const double cA = rd.k[UR_CA - UR_SA], cB = rd.k[UR_CB - UR_SA], dA = rd.k[UR_DA - UR_SA],
-                 dB = rd.k[UR_DB - UR_SA], h = rd.k[UR_H - UR_SA];
-    // (the non-RARE kernels stage only UR_SA.. in LDS: rd.rc is based at UR_SA; fetching these five
-    // as three pairs was tried: +-0)
-    const double g0 = rd.rc[(UR_G0 - UR_SA) * GROUP], g1 = rd.rc[(UR_G1 - UR_SA) * GROUP],
-                 g2 = rd.rc[(UR_G2 - UR_SA) * GROUP], w0 = rd.rc[(UR_W0 - UR_SA) * GROUP],
-                 w1 = rd.rc[(UR_W1 - UR_SA) * GROUP];
-    const double hw = h * fma(w1, e[2], w0);
-    double r = cA * (exA - 1.0);
-    r = fma(cB, exB - 1.0, r);
-    r = fma(g0, e[0], r);
-    r = fma(g1, e[1], r);
-    r = fma(g2, e[2], r);
-    res = fma(hw, e[1], r);
-    tv[0] = fma(dA, exA, g0);
-    tv[1] = fma(dB, exB, g1 + hw);
-    tv[2] = fma(h, e[1], g2);
-    for (int t = 3; t < NT; ++t) tv[t] = 0.0;
-}
-
 template <bool RARE, int NT>
 ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, double exB,
                        double &res, double (&tv)[NT]) {
@@ -750,7 +674,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     int grow_ = lig;     // ... and its row in the row-gathered copies (lanes beyond NN: the all-zero row, Layout::gs;
 #define grow (*(L.gs == GROUP ? &rowid : &grow_))      /* the same number when the copies have 16 rows */
     RowDesc rd;
-    double fqreg[S::FQREG ? NT : 1][S::FQREG ? NNr : 1];
     auto load_rowdesc = [&]() ACME_LAMBDA {
         rd.kind = (lig < NN) ? rowi_s[0 * GROUP + rowid] : RK_NONE;
         rd.erow = rowi_s[1 * GROUP + rowid];
@@ -761,15 +684,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         // the unified rows sA sB cA cB dA dB h
         if constexpr (!S::RCPAIR)
             sfor<0, 8>([&](auto c_) ACME_LAMBDA { rd.k[decltype(c_)::value] = rd.rc[decltype(c_)::value * GROUP]; });
-        if constexpr (S::FQREG) {
-            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
-                constexpr int t = decltype(tc_)::value;
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    fqreg[t][j] = Ms[L.fqr + L.gat(t, j, 0, NN) + (L.pairs ? 2 : 1) * grow];
-                });
-            });
-        }
     };
     load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
@@ -886,9 +800,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         double fqv[NT][NNr + 1];
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
-            if constexpr (S::FQREG) {
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = fqreg[t][decltype(jc)::value]; });
-            } else if constexpr (L.pairs) {
+            if constexpr (L.pairs) {
                 sfor<0, (NN + 1) / 2>([&](auto jc) ACME_LAMBDA {      // two columns per LDS read (Layout::gat)
                     constexpr int j = 2 * decltype(jc)::value;
                     const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * grow]);
@@ -899,7 +811,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = Ms[L.fqr + L.gat(t, decltype(jc)::value, 0, NN) + grow]; });
             }
         });
-        if constexpr (!S::FQREG) wv::sched_fence();
+        wv::sched_fence();
         double e[NT];
         if constexpr (!S::FUSE) {
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
@@ -934,29 +846,25 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             ACME_T2(TB_E2);
             eval_row<true, NT>(rd, e, exA, exB, res, tv);
         } else {
-            double urc[14];
-            if constexpr (S::RCPAIR) {
-                sfor<0, 7>([&](auto pc) ACME_LAMBDA {
-                    constexpr int p = decltype(pc)::value;
-                    const wv::pair_t v = wv::ld2(&rd.rc[p * 2 * GROUP]);
-                    urc[2 * p] = v.lo;
-                    urc[2 * p + 1] = v.hi;
-                });
-            }
-            const double sA = S::RCPAIR ? urc[0] : rd.k[0], sB = S::RCPAIR ? urc[1] : rd.k[1];
+            double urc[14];      // the row's 13 constants, staged in pairs (Shape::RCPAIR)
+            sfor<0, 7>([&](auto pc) ACME_LAMBDA {
+                constexpr int p = decltype(pc)::value;
+                const wv::pair_t v = wv::ld2(&rd.rc[p * 2 * GROUP]);
+                urc[2 * p] = v.lo;
+                urc[2 * p + 1] = v.hi;
+            });
+            const double sA = urc[0], sB = urc[1];
             if (has_bjt) {                                            // sA/sB = 0: exp(0) = 1
-                if constexpr (S::EXPV) exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
-                else exp_junction2(e[0] * sA, e[1] * sB, exA, exB);
+                exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
             } else {
                 // (big shape: this path -- models without a BJT -- keeps the scalar table; on the register
                 // table it costs the two-exponential path 4 spilled registers and 8 % of its speed)
-                if constexpr (S::EXPV && !S::MULT) exA = exp_junction(e[0] * sA, etv);
+                if constexpr (!S::MULT) exA = exp_junction(e[0] * sA, etv);
                 else exA = exp_junction(e[0] * sA);
                 exB = 1.0;
             }
             ACME_T2(TB_E2);
-            if constexpr (S::RCPAIR) eval_row_unified_c<NT>(urc, e, exA, exB, res, tv);
-            else eval_row_unified<NT>(rd, e, exA, exB, res, tv);
+            eval_row_unified_c<NT>(urc, e, exA, exB, res, tv);
         }
         ACME_T2(TB_E3);
         sfor<0, NN>([&](auto jc) ACME_LAMBDA {   // J row = Jq row * fq (src/ACME.jl:186)
@@ -974,11 +882,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         // the row's Jq non-zeros are, short of an overflow of their products with fq -- which turns the
         // elimination's result non-finite and ends the solve the same way (solve_inplace checks).
         double chk = res * 0.0;
-#ifdef ACME_FINITE_FULL
-        sfor<0, NN>([&](auto jc) ACME_LAMBDA { chk = fma(a[decltype(jc)::value], 0.0, chk); });
-#else
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA { chk = fma(tv[decltype(tc_)::value], 0.0, chk); });
-#endif
         unsigned long long bad = S::LITROWS ? wv::ballot(!(chk == 0.0)) & rows4((1ull << NN) - 1ull)
                                             : wv::ballot(lig < NN && !(chk == 0.0));
         return ((bad >> (grp * GROUP)) & 0xFFFFull) == 0ull;
@@ -1176,32 +1080,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             });
         }
         z = sel(need, lz - t, z);
-#ifdef ACME_FLAGS_MASK     /* the flags as lane masks (before: birdie -1.8 %, config 4 -0.4 %, headline +-0) */
-        bool act = need, conv = false, accepted = false;
-        its = 0;
-        ACME_T(TB_SETUP);
-        while (wv::ballot(act)) {
-            its += act ? 1 : 0;
-            bool finite, ok, small;
-            double dz;
-            linearize(z, act, false, finite, ok, small, dz);
-            const bool want = act && finite && ok && small;
-            ACME_DBG("emu newton lane %d it %d act %d finite %d res %g z %.17g", lane, its, (int)act, (int)finite, res, z);
-            const bool stop_bad = act && (!finite || !ok);
-            // hasconverged is evaluated on resmaxabs even after a singular-J return
-            conv = stop_bad ? (finite && small) : conv;
-            accepted = accepted || want;
-            const bool step = act && !stop_bad && !want;
-            z = sel(step, z - dz, z);
-            act = step && (its < A.maxiter);
-            ACME_T(TB_GLUE);
-        }
-        // an accepted iterate stays frozen in z until the loop ends (only stepping lanes move):
-        // it becomes the new extrapolation origin (its J^-1*Jp rows were stored by linearize)
-        lz = sel(accepted, z, lz);
-        lp = sel(accepted, target, lp);
-        return conv || accepted;
-#else
         // the loop-carried per-lane flags as integers in vector registers (bit 0 act, 1 conv, 2 accepted):
         // as 64-bit lane masks they were spilled and re-read through v_writelane / v_readlane every pass
         int fl = wv::keepi(need ? 1 : 0);
@@ -1218,8 +1096,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             const bool step = act && !stop_bad && !want;
             z = sel(step, z - dz, z);
             int nf = fl & ~1;
-            nf = (stop_bad && !(finite && small)) ? (nf & ~2) : nf;
-            nf = (stop_bad && finite && small) ? (nf | 2) : nf;
+            // hasconverged is `resmaxabs < tol` even when solve() returned early because J was non-finite
+            // or singular (src/solvers.jl:203,219-224); `small` is false for a NaN / inf residual
+            nf = stop_bad ? (small ? (nf | 2) : (nf & ~2)) : nf;
             nf = want ? (nf | 4) : nf;
             nf = (step && its < A.maxiter) ? (nf | 1) : nf;
             fl = wv::keepi(nf);
@@ -1229,7 +1108,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         lz = sel(accepted, z, lz);
         lp = sel(accepted, target, lp);
         return (fl & 6) != 0;
-#endif
     };
 
     // solve(::CachingSolver, p) (src/solvers.jl:347-396) around the base solve, with a bounded
@@ -1479,45 +1357,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 if (solve_mode) p = (valid && lig < A.np_io) ? A.p_in[inst * A.np_io + lig] : 0.0;
                 // solve(::HomotopySolver, p) (src/solvers.jl:268-296) as a per-instance
                 // state machine; every base solve is shared by the wave
-#ifdef ACME_HFLAGS_MASK
-                bool need = alive, conv = false;
-                int mode = 0, its_sample = 0;
-                double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
-                ACME_DBG("sample %lld sub %d lane %d p %.17g x %.17g lp %.17g lz %.17g", n, s, lane, p, x[0], lp, lz);
-                ACME_T(TB_PRE);
-                while (wv::ballot(need)) {
-                    int its;
-                    bool c = cached_solve(target, need, its);
-                    ACME_DBG("hom step lane %d need %d mode %d ha %.17g hbest %.17g conv %d its %d", lane, (int)need, mode, ha, hbest, (int)c, its);
-                    its_sample += need ? its : 0;
-                    conv = need ? c : conv;
-                    // the usual case -- every instance that needed a solve got it from the direct
-                    // attempt -- skips the bisection bookkeeping
-                    if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c))) {
-                        need = false;
-                    } else {
-                        bool direct = need && mode == 0;
-                        bool homot = need && mode == 1;
-                        // direct attempt failed -> start bisection from the origin's p
-                        bool start = direct && !c;
-                        startp = sel(start, lp, startp);
-                        // homotopy step bookkeeping
-                        bool hgood = homot && c;
-                        hbest = sel(hgood, ha, hbest);
-                        double new_a = (ha + hbest) / 2.0;
-                        bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
-                        ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
-                        ha = sel(start, 0.5, ha);
-                        hbest = sel(start, 0.0, hbest);
-                        mode = sel(start, 1, mode);
-                        need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
-                        double pa = startp * (1.0 - ha);
-                        pa = pa + ha * p;
-                        target = sel(need, pa, target);
-                    }
-                    ACME_T(TB_HOMO);
-                }
-#else
                 // (need / hasconverged as bits 0 / 1 of an integer in a vector register: see base_solve)
                 int hf = wv::keepi(alive ? 1 : 0);
                 int mode = 0, its_sample = 0;
@@ -1555,7 +1394,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                     ACME_T(TB_HOMO);
                 }
                 const bool conv = (hf & 2) != 0;
-#endif
                 zs[s] = alive ? z : 0.0;
                 if (solve_mode) {   // hand the solver's answer back; no y, no state update
                     if (valid && lig < A.nn_io) A.z_out[inst * A.nn_io + lig] = z;

@@ -6,17 +6,19 @@
 // wave needs for its T samples: what counts is the length of a wave's dependent instruction chain
 // per sample, not how many lanes it keeps busy.  Here a lane owns a whole instance: the nn x nn
 // Jacobian, its LU factors and the solver state live in that lane's registers, there is no
-// cross-lane traffic at all (only wave ballots for the data-dependent loop counts), the model
-// matrices -- the same for every lane -- are read with wave-uniform addresses (scalar loads: they
-// arrive in SGPRs and feed the FMAs directly), and LDS only holds the stored p's of the solution
-// caches.  A sample costs a wave ~1/4 of the instructions of the 16-lane kernel and none of its
+// cross-lane traffic at all (only wave ballots for the data-dependent loop counts), the model's
+// constants -- the same for every lane -- are loaded ONCE per launch into vector registers (LCR below;
+// fetched per use, even by scalar loads, they cost a lone wave more than the arithmetic), and LDS only
+// holds the stored p's of the solution caches where they do not fit the registers (np > 2).  A sample costs a wave ~1/4 of the instructions of the 16-lane kernel and none of its
 // LDS round trips, and the wave advances 64 instances instead of 4.
 //
 // Being free of the row-per-lane layout, the linear algebra here is the reference's own:
 // setlhs! (partial pivoting, first strict maximum, full-row interchange, reciprocal on the
 // diagonal, exact-zero pivot = failure; src/solvers.jl:46-93) and solve! (:95-132), the
-// extrapolated start as  last_z - last_lu \ (last_Jp (p - last_p))  (:209-215), operation for
-// operation.  State, solution caches and reports use the formats of acme_kernel.h, so that
+// extrapolated start as  last_z - last_lu \ (last_Jp (p - last_p))  (:209-215) -- the same operations on
+// the same pivots; only the ORDER of the equations may differ from the reference's (rows are evaluated in
+// the packed position order of acme_pack.h, which can change which of two equal-sized candidates setlhs!
+// meets first).  State, solution caches and reports use the formats of acme_kernel.h, so that
 // acme_batch_solve / get_extrapolation_jacobian (16-lane kernels) keep working on the same batch.
 //
 // Restrictions (the dispatcher in acme_api.inc checks them): one shared model image, one nonlinear
@@ -27,10 +29,7 @@
 namespace acme {
 
 constexpr int LANE_BLOCK = WAVES_PER_BLOCK * 64;   // instances per block (its waves never talk to each other)
-#ifndef ACME_LANE_TILE
-#define ACME_LANE_TILE 8
-#endif
-constexpr int LANE_TILE = ACME_LANE_TILE;   // samples per u / y register tile (64 B per lane and input)
+constexpr int LANE_TILE = 8;   // samples per u / y register tile (64 B per lane and input)
 
 template <class S> struct LaneShape {
     // LDS doubles per block: the stored p's of its instances' solution caches, cp[j][entry][lane]
@@ -125,12 +124,9 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     const long long inst = (long long)wv::bid() * LANE_BLOCK + lane;
     const bool valid = inst < A.n_inst;
     const long long ii = valid ? inst : 0;
-    // The model's constants (LaneLayout block: everything a row needs is contiguous): read-only for
-    // the whole launch and addressed uniformly by the wave -> scalar loads (wv::uniform_ro tells the
-    // compiler so), the values arrive in SGPRs and feed the FMAs as scalar operands.  Each row's
-    // block is re-read where it is used (row_ptr: an offset the optimiser cannot see through): kept
-    // live across the loops, the constants would overflow the 102 SGPRs and come back through
-    // v_readlane, one VALU instruction per use.
+    // The model's constants (LaneLayout block: everything a row needs is contiguous): read-only for the
+    // whole launch and addressed uniformly by the wave, so they are FETCHED by scalar loads
+    // (wv::uniform_ro tells the compiler so) -- once, here -- and then pinned in vector registers.
     constexpr LaneLayout LL = make_lane_layout(NN, NP, NX, NU, NY);
     double LCR[LL.total];                       // register-resident copy (same values in every lane)
     {
@@ -314,9 +310,11 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
         while (wv::ballot(act)) {
             its += act ? 1 : 0;
             const bool finite = evaluate(z);
-            double rmax = 0.0;
-            sfor<0, NN>([&](auto ic) ACME_LAMBDA { rmax = fmax(rmax, fabs(res[decltype(ic)::value])); });
-            const bool small = finite && rmax < A.tol;
+            // resmaxabs < tol (src/solvers.jl:203,218): false for a NaN / inf residual, and independent of
+            // whether J is finite (solve() returns early then, hasconverged still looks at the residual alone)
+            int small_i = 1;
+            sfor<0, NN>([&](auto ic) ACME_LAMBDA { small_i &= (int)(fabs(res[decltype(ic)::value]) < A.tol); });
+            const bool small = small_i != 0;
             double dz[NN];
             sfor<0, NN>([&](auto ic) ACME_LAMBDA { dz[decltype(ic)::value] = res[decltype(ic)::value]; });
             const bool ok = lane_lu_factor<NN>(jm, ipiv);       // LU before the convergence test (:223-226)
@@ -431,7 +429,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     // does not have re-read input 0 -- a branch per entry costs more than the loads)
     auto fetch = [&](long long n0, double (&dst)[LANE_TILE * NUr]) ACME_LAMBDA {
         sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA { dst[decltype(ec)::value] = 0.0; });
-        if (valid && n0 < T) {
+        if (valid && n0 < T && nu_io > 0) {      // (a model without inputs has u == NULL: run!(model, zeros(0, T)))
             sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA {
                 constexpr int e = decltype(ec)::value;
                 const long long n = n0 + e / NUr;

@@ -58,15 +58,15 @@ class SubProblem:
 class DiscreteModel:
     """``DiscreteModel(circ, t, Solver; decompose_nonlinearity=true)`` (src/ACME.jl:150).
 
-    ``solver`` defaults to ``HomotopySolver{SimpleSolver}``.  The reference's default additionally
-    wraps a ``CachingSolver`` (a per-stream, unboundedly growing k-d tree of stored solutions that
-    only changes Newton's start point): ``solver=CachingHomotopySolver`` selects the GPU's
-    bounded variant of it (the last 16 stored solutions per instance, same lookup and storing
-    rules; converged results agree within the solver tolerance, iteration counts follow the
-    oracle's bounded variant).
+    ``solver`` defaults, like the reference's third positional argument, to
+    ``HomotopySolver{CachingSolver{SimpleSolver}}`` (src/ACME.jl:150).  On the GPU the ``CachingSolver``
+    (src/solvers.jl:303-405: a per-stream, unboundedly growing k-d tree of stored solutions that only
+    changes Newton's start point) keeps the last 16 stored solutions per instance (same lookup and
+    storing rules; converged results agree within the solver tolerance, iteration counts follow the
+    oracle's bounded variant).  ``solver=HomotopySolver`` / ``SimpleSolver`` select the cache-less stacks.
     """
 
-    def __init__(self, circ=None, t=None, solver=HomotopySolver, decompose_nonlinearity=True,
+    def __init__(self, circ=None, t=None, solver=CachingHomotopySolver, decompose_nonlinearity=True,
                  _data=None):
         if solver not in SOLVER_IDS:
             raise ValueError(f"unknown solver {solver!r}")
@@ -162,7 +162,7 @@ class DiscreteModel:
 
     @classmethod
     def from_dict(cls, d, solver=None):
-        return cls(solver=solver or d.get("solver", HomotopySolver), _data=d)
+        return cls(solver=solver or d.get("solver", CachingHomotopySolver), _data=d)
 
     def save(self, path):
         with open(path, "w") as fh:

@@ -31,7 +31,7 @@ from . import ratmat as rm
 from .batchval import BVal, DD, values
 from .circuit import KIND_BJT, KIND_DIODE, KIND_POT
 from .hostsolve import eval_table
-from .model import DiscreteModel, HomotopySolver
+from .model import CachingHomotopySolver, DiscreteModel, HomotopySolver
 
 
 # ---------------------------------------------------------------------------------------------
@@ -218,7 +218,7 @@ class BatchModels:
     ``ModelRunner(models=...)`` needs for per-instance matrices.  ``model(i)`` materialises
     instance i as an ordinary ``DiscreteModel``."""
 
-    def __init__(self, data, n, solver=HomotopySolver):
+    def __init__(self, data, n, solver=CachingHomotopySolver):
         self.d, self.n, self.solver = data, n, solver
 
     def __len__(self):
@@ -241,7 +241,7 @@ class BatchModels:
         return (self.model(i) for i in range(self.n))
 
 
-def derive_batch(make_circuit, t, component_values, solver=HomotopySolver, decompose_nonlinearity=True,
+def derive_batch(make_circuit, t, component_values, solver=CachingHomotopySolver, decompose_nonlinearity=True,
                  init_on_device=None):
     """``make_circuit(value)`` builds the circuit, calling ``value(name, nominal)`` for every
     component that carries a tolerance (e.g. ``examples.superover(..., value=value)``).

@@ -153,10 +153,16 @@ def _cpu_worker(args):
     solver state, empty solution cache) and, if `warm`, a second pass continuing it -- the regime the
     GPU's timed steps are in (bench.py warms the GPU runner up with the same signal first)."""
     fixture, rows, T, solver, warm, reflib = args
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from oracle import refpy
+    from oracle.refpy import RefRunner
     if reflib:
         os.environ["ACME_REF_LIB"] = reflib
-    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
-    from oracle.refpy import RefRunner
+    else:
+        os.environ.pop("ACME_REF_LIB", None)
+    # the build that is about to be timed IS the one asked for (refpy caches per resolved path)
+    want = os.path.realpath(reflib) if reflib else os.path.realpath(os.path.join(ROOT, "oracle", "libacme_ref.so"))
+    assert refpy.lib().acme_path == want, (refpy.lib().acme_path, want)
     m = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
     cold = warm_t = 0.0
     iters = iters_warm = 0
@@ -231,9 +237,13 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
         # leg 1 (the headline CPU figure, as in round 1): -O2 build, cold streams; its second pass
         # over the same signal gives the warm-state figure
         res = pool.map(_cpu_worker, jobs(True, None), chunksize=1)
-        # leg 2: the same source built -O3 -march=native on this host, on a third of the streams
-        native = build_native_oracle()
-        res_n = pool.map(_cpu_worker, jobs(True, native, stride=3), chunksize=1) if native else None
+    # leg 2: the same source built -O3 -march=native on this host, on a third of the streams -- in FRESH
+    # worker processes (and _cpu_worker asserts which build it has loaded)
+    native = build_native_oracle()
+    res_n = None
+    if native:
+        with mp.get_context("fork").Pool(cores) as pool:
+            res_n = pool.map(_cpu_worker, jobs(True, native, stride=3), chunksize=1)
     if native:
         try:
             os.remove(native)

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}      # resolved path -> loaded library (ACME_REF_LIB may change between calls: bench.py's native leg)
 
 SOLVER_IDS = {"SimpleSolver": 0, "HomotopySolver{SimpleSolver}": 1,
               "HomotopySolver{CachingSolver{SimpleSolver}}": 2}
@@ -31,11 +31,11 @@ def build():
 
 
 def lib():
-    global _LIB
-    if _LIB is None:
-        # ACME_REF_LIB: file name of the build to load (bench.py times libacme_ref_native.so, the
-        # -O3 -march=native build of the same source, as a second CPU leg)
-        path = os.path.join(_HERE, os.environ.get("ACME_REF_LIB", "libacme_ref.so"))
+    # ACME_REF_LIB: file name of the build to load (bench.py times a -O3 -march=native build of the
+    # same source as a second CPU leg); looked up on EVERY call and cached per resolved path, so that a
+    # process which already holds the default build still gets the one it asks for
+    path = os.path.realpath(os.path.join(_HERE, os.environ.get("ACME_REF_LIB", "libacme_ref.so")))
+    if path not in _LIBS:
         src = os.path.join(_HERE, "acme_ref.c")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()
@@ -64,8 +64,9 @@ def lib():
         L.acme_ref_lu_factor.argtypes = [C.c_int, dp, ip]
         L.acme_ref_lu_solve.argtypes = [C.c_int, dp, ip, dp]
         L.acme_ref_eval_element.argtypes = [C.c_int, dp, dp, dp, dp]
-        _LIB = L
-    return _LIB
+        L.acme_path = path
+        _LIBS[path] = L
+    return _LIBS[path]
 
 
 def _dp(a):

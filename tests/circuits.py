@@ -72,6 +72,19 @@ def resistor_diode_circuit():
     return c, v_d
 
 
+def constant_source_clipper(v=0.8):
+    """A diode clipper fed by a CONSTANT voltage source: a nonlinear model with a state but no
+    inputs (nn = 2, np = 1, nx = 1, nu = 0), run in the reference as run!(model, zeros(0, T))."""
+    return build([
+        ("j_in", voltagesource(v), {"-": "gnd"}),
+        ("r1", resistor(1e3), {1: ("j_in", "+")}),
+        ("c1", capacitor(47e-9), {1: ("r1", 2), 2: "gnd"}),
+        ("d1", diode(is_=1e-15), {"-": "gnd", "+": ("r1", 2)}),
+        ("d2", diode(is_=1.8e-15), {"-": ("r1", 2), "+": "gnd"}),
+        ("j_out", voltageprobe(), {"-": "gnd", "+": ("r1", 2)}),
+    ])
+
+
 def no_solution_circuit():
     """test/runtests.jl:170-176: diode driven by a current source."""
     c = Circuit()

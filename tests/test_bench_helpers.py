@@ -69,3 +69,26 @@ def test_drive_one_corner_is_singular():
                 assert r.report.n_warn >= T - 5 and r.report.iters_total > 300 * T
             else:
                 assert r.report.n_warn == 0 and r.report.iters_total < 20 * T
+
+
+def test_native_cpu_leg_times_the_native_build():
+    """The '-O3 -march=native' leg of cpu_baseline must really load that build, also in a process that
+    already holds the default -O2 library (it once silently re-timed the -O2 build)."""
+    import os
+    import bench
+    from oracle import refpy
+    os.environ.pop("ACME_REF_LIB", None)
+    default = refpy.lib()
+    native = bench.build_native_oracle()
+    assert native is not None
+    try:
+        sig = np.zeros((1, 8))
+        # _cpu_worker asserts that the library it is about to time is the one requested
+        bench._cpu_worker(("diodeclipper", [sig], 8, None, False, native))
+        assert os.environ.get("ACME_REF_LIB") == native
+        assert refpy.lib().acme_path == os.path.realpath(native) and refpy.lib() is not default
+        bench._cpu_worker(("diodeclipper", [sig], 8, None, False, None))
+        assert refpy.lib() is default
+    finally:
+        os.environ.pop("ACME_REF_LIB", None)
+        os.remove(native)

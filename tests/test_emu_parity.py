@@ -246,7 +246,7 @@ def test_emulated_steadystate_per_instance_inputs(emu_lib):
     np.testing.assert_allclose(x, X, rtol=1.5e-8, atol=1e-14)
 
 
-def _simplified_superover(var):
+def _simplified_superover(var, solver="HomotopySolver{SimpleSolver}"):
     """test/runtests.jl:751-756 / :782-787: superover with vb forced by an ideal source ->
     the nonlinearity decomposes into 3 (fixed pots) / 4 (pots as inputs) sub-problems."""
     from fractions import Fraction
@@ -257,7 +257,7 @@ def _simplified_superover(var):
     c.add("vbsrc", voltagesource(4.5))
     c.connect(("vbsrc", "+"), "vb")
     c.connect(("vbsrc", "-"), "gnd")
-    return DiscreteModel(c, Fraction(1 / 44100))
+    return DiscreteModel(c, Fraction(1 / 44100), solver)
 
 
 def test_emulated_decomposed_nonlinearity(emu_lib):
@@ -417,3 +417,36 @@ def test_emulated_time_major_run(emu_lib):
         r2.run(ut[:, :, :3], time_major=True)
     with pytest.raises(DimensionMismatch):
         r2.run(ut, np.empty((3, 59, 1)), time_major=True)
+
+
+@pytest.mark.parametrize("lane_kernel", ["1", "0"])
+def test_emulated_nonlinear_model_without_inputs(emu_lib, lane_kernel, monkeypatch):
+    """run!(model, zeros(0, T)) on a nonlinear model with a state and NO inputs (u is NULL at the C ABI):
+    both run kernels, the lane-per-instance one and the 16-lane one."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    monkeypatch.setenv("ACME_LANE_KERNEL", lane_kernel)
+    m = DiscreteModel(circuits.constant_source_clipper(0.8), Fraction(1, 44100))
+    assert (m.nu, m.nx) == (0, 1) and m.subs[0].nn == 2
+    u = np.zeros((2, 0, 20))
+    y = emu_runner(emu_lib, m, 2).run(u)
+    yref, _ = oracle_run(m, u)
+    assert_close(y, yref, rtol=1e-12)
+    assert 0.6 < y[0, 0, -1] < 0.7          # the capacitor charges to the diode's forward voltage
+
+
+@pytest.mark.parametrize("name,N,T", [("diodeclipper", 19, 200), ("birdie_fixed", 4, 200)])
+def test_emulated_small_shapes_both_run_kernels(emu_lib, name, N, T, monkeypatch):
+    """The shapes the lane-per-instance kernel takes by default also run -- and give the same answer to
+    rounding -- in the 16-lane kernel (ACME_LANE_KERNEL=0: the A/B fallback, and the code path of
+    acme_batch_solve / the Jacobian export on such batches)."""
+    m = load(name)
+    u = sweep_inputs(name, N, T)
+    ys = {}
+    for k in ("1", "0"):
+        monkeypatch.setenv("ACME_LANE_KERNEL", k)
+        ys[k] = emu_runner(emu_lib, m, N).run(u)
+    yref, _ = oracle_run(m, u)
+    assert_close(ys["1"], yref, rtol=1e-12)
+    assert_close(ys["0"], yref, rtol=1e-12)

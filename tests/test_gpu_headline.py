@@ -162,7 +162,7 @@ def test_reference_test_input_pot_ramps(hip_lib):
 
 def test_config4_full_width(hip_lib):
     """BASELINE config 4's per-GPU share at full width: 8192 private model blocks (Monte-Carlo
-    component tolerances, PCG64 seed 20250905; two LDS rounds of 256 blocks), default stack,
+    component tolerances, PCG64 seed 20250905; 512 blocks, two per CU: ONE round), default stack,
     through size-independent properties -- block-split invariance and instance-permutation
     invariance, bit for bit -- plus 8 spot instances against oracle runs of EXACTLY derived
     per-instance models."""
@@ -188,7 +188,7 @@ def test_config4_full_width(hip_lib):
     r2 = ModelRunner(batch.model(0), N, models=batch, lib=hip_lib)
     y2 = torch.cat([r2.run_torch(u[:, a:b].contiguous()) for a, b in ((0, 401), (401, T))], dim=1)
     assert torch.equal(y1, y2)
-    # the same circuits in another order: other wave-mates, other LDS round, same arithmetic
+    # the same circuits in another order: other wave-mates, another CU, same arithmetic
     perm = np.random.default_rng(4).permutation(N)
     pvals = {k: v[perm] for k, v in vals.items()}
     pbatch = derive_batch(make, Fraction(1, 44100), pvals)

@@ -120,7 +120,7 @@ def test_failure_semantics(hip_lib):
     import circuits
     from acme_jl_amd.model import DiscreteModel
     from acme_jl_amd.runner import AcmeError
-    m = DiscreteModel(circuits.no_solution_circuit(), Fraction(1))
+    m = DiscreteModel(circuits.no_solution_circuit(), Fraction(1), "HomotopySolver{SimpleSolver}")
     r = runner(hip_lib, m, 3)
     u = np.array([[[1.0, 1.0]], [[-1.0, -1.0]], [[1.0, 1.0]]])
     with warnings.catch_warnings(record=True) as w:
@@ -158,7 +158,7 @@ def test_per_instance_matrices(hip_lib):
         c = examples.diodeclipper()
         c.elements["r1"] = resistor(1e3 * (1 + 0.005 * (k - 10)))
         c.elements["c1"] = capacitor(47e-9 * (1 - 0.003 * (k - 10)))
-        models.append(DiscreteModel(c, Fraction(1, 44100)))
+        models.append(DiscreteModel(c, Fraction(1, 44100), "HomotopySolver{SimpleSolver}"))
     u = sweep_inputs("diodeclipper", 21, 1000)
     y = ModelRunner(models[0], 21, models=models, lib=hip_lib).run(u)
     for k in range(21):
@@ -269,12 +269,12 @@ def test_monte_carlo_per_instance_superover(hip_lib):
     rng = np.random.Generator(np.random.PCG64(20250905))
     N = 40
     vals = {k: v * (1 + 0.05 * rng.uniform(-1, 1, N)) for k, v in nominal.items()}
-    batch = derive_batch(make, Fraction(1, 44100), vals)
+    batch = derive_batch(make, Fraction(1, 44100), vals, solver="HomotopySolver{SimpleSolver}")
     u = np.tile(sine(800)[None, None, :], (N, 1, 1))
     r = ModelRunner(batch.model(0), N, models=batch, lib=hip_lib)
     y = r.run(u)
     for k in (0, 7, 16, 39):
-        exact = DiscreteModel(make(lambda name, v: float(vals[name][k])), Fraction(1, 44100))
+        exact = DiscreteModel(make(lambda name, v: float(vals[name][k])), Fraction(1, 44100), "HomotopySolver{SimpleSolver}")
         yref, _ = oracle_run(exact, u[k:k + 1])
         assert_close(y[k:k + 1], yref)
     assert np.abs(y[0] - y[1]).max() > 1e-6      # the instances really are different circuits

@@ -6,6 +6,7 @@ import numpy as np
 
 from acme_jl_amd import examples
 from acme_jl_amd.model import DiscreteModel
+from acme_jl_amd.model import HomotopySolver
 from acme_jl_amd.montecarlo import derive_batch
 from helpers import assert_close, oracle_run, sine
 
@@ -27,11 +28,11 @@ def _rel(a, b):
 def test_batch_derivation_matches_exact_superover():
     make = lambda value: examples.superover(1.0, 1.0, 1.0, value=value)     # noqa: E731
     vals = _tolerances(make, 5)
-    bm = derive_batch(make, T44, vals)
+    bm = derive_batch(make, T44, vals, solver=HomotopySolver)
     assert (bm.d["nns"], bm.d["nqs"], bm.d["nps"]) == ([7], [14], [5])      # test/runtests.jl:744
     u = np.tile(sine(300)[None, None, :], (1, 1, 1))
     for i in (0, 2, 4):
-        exact = DiscreteModel(make(lambda name, v: float(vals[name][i])), T44)
+        exact = DiscreteModel(make(lambda name, v: float(vals[name][i])), T44, HomotopySolver)
         m = bm.model(i)
         for k in ("a", "b", "c", "x0", "dy", "ey", "fy", "y0"):
             assert _rel(getattr(exact, k), getattr(m, k)) < 1e-9, k
@@ -48,12 +49,12 @@ def test_batch_derivation_variable_pots_and_decomposition():
     """np pins of the varying-pot superover (test/runtests.jl:777) and a decomposed model."""
     make = lambda value: examples.superover(value=value)                    # noqa: E731
     vals = _tolerances(make, 3)
-    bm = derive_batch(make, T44, vals)
+    bm = derive_batch(make, T44, vals, solver=HomotopySolver)
     assert (bm.d["nns"], bm.d["nqs"], bm.d["nps"]) == ([13], [29], [11])
     u = np.zeros((1, 4, 200))
     u[0, 0] = sine(200)
     u[0, 1:] = np.array([0.4, 0.7, 0.2])[:, None]
-    exact = DiscreteModel(make(lambda name, v: float(vals[name][1])), T44)
+    exact = DiscreteModel(make(lambda name, v: float(vals[name][1])), T44, HomotopySolver)
     yb, _ = oracle_run(bm.model(1), u)
     ye, _ = oracle_run(exact, u)
     assert_close(yb, ye, rtol=1e-9)
@@ -63,10 +64,10 @@ def test_batch_models_run_on_emulated_kernel(emu_lib):
     from acme_jl_amd.runner import ModelRunner
     make = lambda value: examples.superover(1.0, 1.0, 1.0, value=value)     # noqa: E731
     vals = _tolerances(make, 4)
-    bm = derive_batch(make, T44, vals)
+    bm = derive_batch(make, T44, vals, solver=HomotopySolver)
     u = np.tile(sine(200)[None, None, :], (4, 1, 1))
     y = ModelRunner(bm.model(0), 4, models=bm, lib=emu_lib).run(u)
     for i in range(4):
-        exact = DiscreteModel(make(lambda name, v: float(vals[name][i])), T44)
+        exact = DiscreteModel(make(lambda name, v: float(vals[name][i])), T44, HomotopySolver)
         ye, _ = oracle_run(exact, u[i:i + 1])
         assert_close(y[i:i + 1], ye, rtol=1e-9)
