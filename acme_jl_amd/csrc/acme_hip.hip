@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -191,6 +193,7 @@ static inline int event_destroy(event_t e) { return (int)hipEventDestroy(e); }
 static inline int event_record(event_t e, stream_t st) { return (int)hipEventRecord(e, st); }
 static inline int event_sync(event_t e) { return (int)hipEventSynchronize(e); }
 static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)hipEventElapsedTime(ms, a, b); }
+static inline std::mutex *run_mutex() { return nullptr; }     // HIP: runs of distinct batches are concurrent
 }  // namespace be
 
 #include "acme_api.inc"

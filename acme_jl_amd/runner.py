@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
+    "acme_batch_run_async", "acme_batch_wait",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
@@ -109,6 +110,8 @@ class Library:
         L.acme_batch_destroy.restype = None
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
+        L.acme_batch_run_async.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
+        L.acme_batch_wait.argtypes = [vp]
         L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_get_extrapolation_jacobian.argtypes = [vp, C.c_int, dp, C.c_int, vp]
         L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -307,6 +310,30 @@ class ModelRunner:
             return y
         return np.asfortranarray(out[0]) if single else np.ascontiguousarray(out)
 
+    def run_async(self, u, y):
+        """``acme_batch_run_async`` on host buffers in the ABI's layout: ``u`` (N, T, nu) and ``y``
+        (N, T, ny), C-contiguous float64 (slices of larger arrays along the first axis are fine).
+        Returns at once; ``wait()`` joins the run.  The caller keeps ``u`` / ``y`` alive until then."""
+        m = self.model
+        for a, cols, what in ((u, m.nu, "u"), (y, m.ny, "y")):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+                raise TypeError(f"{what} must be a C-contiguous float64 array")
+            if a.ndim != 3 or a.shape[0] != self.n or a.shape[2] != cols:
+                raise DimensionMismatch(f"{what} must have shape ({self.n}, T, {cols})")
+        self._check_io(u.shape[2], y.shape[2], u.shape[1], y.shape[1])
+        self._inflight = (u, y)
+        self.lib.check(self.lib.L.acme_batch_run_async(self.h, u.ctypes.data, y.ctypes.data, u.shape[1],
+                                                       ACME_MEM_HOST, None))
+
+    def wait(self, check=True):
+        """``acme_batch_wait``: join the run started by ``run_async``; raises what it failed with."""
+        try:
+            self.lib.check(self.lib.L.acme_batch_wait(self.h))
+        finally:
+            self._inflight = None
+        if check:
+            self.check()
+
     def run_device(self, u_ptr, y_ptr, T, stream=None):
         """Raw asynchronous launch: ``u_ptr``/``y_ptr`` are device addresses of
         [N][T][nu] / [N][T][ny] float64 buffers on this runner's GPU."""
@@ -420,6 +447,65 @@ class ModelRunner:
 
     def kernel_shape(self):
         return self._mh.kernel_shape()
+
+
+class MultiDeviceRunner:
+    """N instances of a model spread over several GPUs of ONE node by ONE process: contiguous instance
+    ranges (``dist.shard_range``), one ``ModelRunner`` per device, every run started asynchronously on all
+    of them (``acme_batch_run_async``) and then joined, each batch reading and writing its own slice of
+    the caller's ``u`` / ``y``.  No collective is involved -- the sweep shards perfectly -- so this is the
+    multi-GPU path of a host that has no torch.distributed (the Julia binding's ``MultiBatchRunner`` is
+    the same thing over the same C ABI).  ``devices``: HIP ordinals, default all visible ones; an ordinal
+    may repeat (several batches on one GPU), which is how the path is tested on a single-GPU box."""
+
+    def __init__(self, model, n_instances, devices=None, lib=None, models=None):
+        from .dist import shard_range
+        self.lib = lib or default_library()
+        if devices is None:
+            devices = list(range(self.lib.device_count()))
+        if not devices:
+            raise AcmeError("no HIP device available; acme_jl_amd has no CPU fallback")
+        self.model, self.n, self.devices = model, int(n_instances), list(devices)
+        self.ranges = [shard_range(self.n, k, len(self.devices)) for k in range(len(self.devices))]
+        self.runners = []
+        for dev, (lo, hi) in zip(self.devices, self.ranges):
+            if hi > lo:
+                part = None if models is None else [models[i] for i in range(lo, hi)]
+                self.runners.append(ModelRunner(model, hi - lo, device=dev, lib=self.lib, models=part))
+            else:
+                self.runners.append(None)
+
+    def run(self, u, y=None, check=True):
+        """``u``: (N, T, nu) C-contiguous float64 (the ABI's layout); returns / fills ``y`` (N, T, ny)."""
+        m = self.model
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if u.ndim != 3 or u.shape[0] != self.n or u.shape[2] != m.nu:
+            raise DimensionMismatch(f"input must have shape ({self.n}, T, {m.nu})")
+        if y is None:
+            y = np.empty((self.n, u.shape[1], m.ny), dtype=np.float64)
+        elif y.shape != (self.n, u.shape[1], m.ny) or y.dtype != np.float64 or not y.flags.c_contiguous:
+            raise DimensionMismatch(f"output must be a C-contiguous float64 array of shape ({self.n}, {u.shape[1]}, {m.ny})")
+        started, err = [], None
+        for r, (lo, hi) in zip(self.runners, self.ranges):
+            if r is not None:
+                r.run_async(u[lo:hi], y[lo:hi])
+                started.append(r)
+        for r in started:                       # join every run, then report the first failure
+            try:
+                r.wait(check=check)
+            except AcmeError as e:
+                err = err or e
+        if err is not None:
+            raise err
+        return y
+
+    def report_arrays(self):
+        parts = [r.report_arrays() for r in self.runners if r is not None]
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+    def get_state(self):
+        parts = [r.get_state() for r in self.runners if r is not None]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
 
 
 def run(model_or_runner, u, **kw):

@@ -194,6 +194,29 @@ def build_native_oracle():
         return None
 
 
+def julia_probe(seconds=1.0, streams=4, timeout=900):
+    """is there a `julia` on this box?  If so, time the REAL reference's run! (and push
+    the doctest through julia/ACMEHip.jl) with julia/bench_reference.jl.  Returns None when Julia is absent
+    (the case on every box seen so far), else a dict: the script's JSON line, or what went wrong."""
+    import shutil
+    import subprocess
+    exe = shutil.which("julia")
+    if exe is None:
+        return None
+    rec = {"julia": exe}
+    try:
+        out = subprocess.run([exe, "--startup-file=no", os.path.join(ROOT, "julia", "bench_reference.jl"), ROOT,
+                              str(seconds), str(streams)], capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode == 0 and lines:
+            rec.update(json.loads(lines[-1]))
+        else:
+            rec["error"] = (out.stderr or out.stdout)[-400:]
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        rec["error"] = repr(e)
+    return rec
+
+
 def host_cores():
     """CPUs this process may really use: min(affinity, cgroup quota) -- `nproc` on the GPU box
     reports the whole host (256) while the container is limited to a 16-CPU quota."""
@@ -496,11 +519,17 @@ def main():
                                    "valu_issue_profiled_kernel_ms -- warm-up launches included, hence above kernel_ms); null if none",
             },
         }
+        if use_dist and not rehearsal:
+            assert out["config"]["rccl_ranks"] == args.gpus == dist.get_world_size(), (world, args.gpus)
+            assert dist.get_backend() == "nccl"
+            assert len(set(checksums)) == world, f"ranks computed identical shards: {checksums}"
         if out["roofline"]["fp64_tflops"] is not None:
             out["roofline"]["fp64_frac"] = out["roofline"]["fp64_tflops"] / FP64_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             T_cpu = args.cpu_samples or min(T, FS)
             out["cpu_baseline"] = cpu_baseline(fixture, model, pots, amp, T_cpu, fs=fs)
+            # the real reference, if this box has a Julia (null: `julia` not on PATH)
+            out["cpu_baseline"]["julia"] = julia_probe()
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -143,6 +143,17 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
                    void *stream);
 
+/* acme_batch_run without blocking the caller: the same run on a worker thread of the library (a
+ * host-buffer run drives its time-slice pipeline from there).  ONE host thread can thereby keep one
+ * batch per GPU of a node busy -- start all, then acme_batch_wait each -- which is how a single
+ * (Julia) process uses the 8 GPUs of a node without any collective: contiguous instance ranges, every
+ * batch reading and writing its own slice of the caller's u / y.  At most one run is in flight per
+ * batch; every other entry point taking the batch first waits for it.  u / y must stay valid until
+ * acme_batch_wait, which returns the run's status (acme_last_error() then holds its message). */
+int acme_batch_run_async(acme_batch *b, const double *u, double *y, long long T, int mem,
+                         void *stream);
+int acme_batch_wait(acme_batch *b);
+
 /* The solver plugin contract, batched (src/solvers.jl:207-236, 268-302): for every instance
  *   z = solve(solver, p); converged = hasconverged(solver); iters = needediterations(solver)
  * on sub-problem `sub` (0-based): p is [N][np_sub], z is [N][nn_sub], converged/iters are [N].  Like the reference's

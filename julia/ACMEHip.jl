@@ -33,7 +33,7 @@ using LinearAlgebra: I
 import ACME: run!, solve, hasconverged, needediterations, set_resabstol!,
              get_extrapolation_origin, set_extrapolation_origin, get_extrapolation_jacobian
 
-export BatchRunner, GPUBatchSolver, element_table
+export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table
 
 const lib = get(ENV, "ACME_HIP_LIB", "libacme_hip.so")
 
@@ -64,6 +64,8 @@ end
 
 lasterror() = unsafe_string(ccall((:acme_last_error, lib), Cstring, ()))
 check(rc) = rc < 0 ? error("libacme_hip: " * lasterror()) : rc
+"number of HIP devices the library sees"
+device_count() = Int(ccall((:acme_device_count, lib), Cint, ()))
 
 # ---- closures -> element table -----------------------------------------------------------------
 "captured variable `name` of closure `f` (unwrapping the Box of a re-assigned capture)"
@@ -243,19 +245,19 @@ end
 [N][T][nu] layout): slice `[:, :, i]` is exactly the matrix `ACME.run!` takes for instance `i`.
 Errors and warnings follow `step!` (src/ACME.jl:688-694) and `checkiosizes` (:625-635).
 """
-function run!(r::BatchRunner, y::Array{Float64,3}, u::Array{Float64,3})
-    m = r.model
+function checkiosizes(m::DiscreteModel, n::Integer, y::Array{Float64,3}, u::Array{Float64,3})      # src/ACME.jl:625-635
     size(u, 1) == ACME.nu(m) || throw(DimensionMismatch("input matrix has $(size(u,1)) rows, but model has $(ACME.nu(m)) inputs"))
     size(y, 1) == ACME.ny(m) || throw(DimensionMismatch("output matrix has $(size(y,1)) rows, but model has $(ACME.ny(m)) outputs"))
     size(u, 2) == size(y, 2) || throw(DimensionMismatch("input matrix has $(size(u,2)) columns, output matrix has $(size(y,2)) columns"))
-    (size(u, 3) == r.n && size(y, 3) == r.n) || throw(DimensionMismatch("u and y need one nu × T (ny × T) slice per instance ($(r.n))"))
-    check(ccall((:acme_batch_run, lib), Cint,
-                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Clonglong, Cint, Ptr{Cvoid}),
-                r.h, u, y, size(u, 2), ACME_MEM_HOST, C_NULL))
+    (size(u, 3) == n && size(y, 3) == n) || throw(DimensionMismatch("u and y need one nu × T (ny × T) slice per instance ($n)"))
+end
+
+"the policy of `step!` (src/ACME.jl:688-694) on the reports a run left behind; `offset`: instances before this batch"
+function checkreports!(r::BatchRunner, offset::Integer=0)
     reps = reports(r)
     bad = findfirst(rep -> rep.first_nonfinite >= 0, reps)
     bad === nothing || error("Failed to converge while solving non-linear equation, got non-finite result. " *
-                             "(instance $bad, sample $(reps[bad].first_nonfinite + 1))")
+                             "(instance $(offset + bad), sample $(reps[bad].first_nonfinite + 1))")
     nwarn = sum(rep -> rep.n_warn, reps)
     if nwarn > r.warned
         @warn "Failed to converge while solving non-linear equation."
@@ -264,11 +266,87 @@ function run!(r::BatchRunner, y::Array{Float64,3}, u::Array{Float64,3})
     return nothing
 end
 
+function run!(r::BatchRunner, y::Array{Float64,3}, u::Array{Float64,3})
+    checkiosizes(r.model, r.n, y, u)
+    check(ccall((:acme_batch_run, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Clonglong, Cint, Ptr{Cvoid}),
+                r.h, u, y, size(u, 2), ACME_MEM_HOST, C_NULL))
+    return checkreports!(r)
+end
+
 function run!(r::BatchRunner, u::Array{Float64,3})
     y = Array{Float64,3}(undef, ACME.ny(r.model), size(u, 2), r.n)
     run!(r, y, u)
     return y
 end
+
+# ---- MultiBatchRunner: N instances over the GPUs of one node, one Julia process -----------------------
+"contiguous instance range (1-based) of part `k` of `parts`; sizes differ by at most one (acme_jl_amd/dist.py)"
+function shard_range(n::Integer, k::Integer, parts::Integer)
+    base, rem = divrem(n, parts)
+    lo = (k - 1) * base + min(k - 1, rem)
+    return lo+1:lo+base+(k <= rem ? 1 : 0)
+end
+
+"""
+    MultiBatchRunner(model, n; devices=0:device_count()-1, solver=..., per_instance_matrices=false)
+
+`n` instances of `model` spread over several GPUs by ONE process: contiguous instance ranges, one
+`BatchRunner` per device.  `run!` starts every device's run asynchronously (`acme_batch_run_async`: the
+library drives each from a worker thread of its own) and then joins them (`acme_batch_wait`); every
+batch reads and writes its own `[:, :, range]` slice of `u` / `y` in place.  The sweep shards perfectly
+(instances never interact), so there is no collective and no MPI/RCCL dependency on the Julia side.
+"""
+struct MultiBatchRunner
+    model::DiscreteModel
+    n::Int
+    runners::Vector{BatchRunner}
+    ranges::Vector{UnitRange{Int}}
+end
+
+function MultiBatchRunner(model::DiscreteModel, n::Integer; devices=0:device_count()-1, kwargs...)
+    isempty(devices) && error("libacme_hip: no HIP device available")
+    ranges = [shard_range(n, k, length(devices)) for k in 1:length(devices)]
+    keep = [k for k in 1:length(devices) if !isempty(ranges[k])]
+    runners = [BatchRunner(model, length(ranges[k]); device=devices[k], kwargs...) for k in keep]
+    return MultiBatchRunner(model, n, runners, ranges[keep])
+end
+
+function run!(mr::MultiBatchRunner, y::Array{Float64,3}, u::Array{Float64,3})
+    checkiosizes(mr.model, mr.n, y, u)
+    T = size(u, 2)
+    su, sy = size(u, 1) * T, size(y, 1) * T                   # doubles per instance
+    GC.@preserve u y begin
+        started = 0
+        rcs, msg = Cint[], ""                                 # (assigned in the finally clause below)
+        try
+            for (r, rg) in zip(mr.runners, mr.ranges)
+                check(ccall((:acme_batch_run_async, lib), Cint,
+                            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Clonglong, Cint, Ptr{Cvoid}),
+                            r.h, pointer(u) + 8 * su * (first(rg) - 1), pointer(y) + 8 * sy * (first(rg) - 1),
+                            T, ACME_MEM_HOST, C_NULL))
+                started += 1
+            end
+        finally                                               # never leave a run in flight behind
+            rcs = [ccall((:acme_batch_wait, lib), Cint, (Ptr{Cvoid},), r.h) for r in mr.runners[1:started]]
+            msg = lasterror()
+        end
+        all(rc -> rc >= 0, rcs) || error("libacme_hip: " * msg)
+    end
+    for (r, rg) in zip(mr.runners, mr.ranges)
+        checkreports!(r, first(rg) - 1)
+    end
+    return nothing
+end
+
+function run!(mr::MultiBatchRunner, u::Array{Float64,3})
+    y = Array{Float64,3}(undef, ACME.ny(mr.model), size(u, 2), mr.n)
+    run!(mr, y, u)
+    return y
+end
+
+reports(mr::MultiBatchRunner) = reduce(vcat, [reports(r) for r in mr.runners])
+set_resabstol!(mr::MultiBatchRunner, tol) = (foreach(r -> set_resabstol!(r, tol), mr.runners); tol)
 
 set_resabstol!(r::BatchRunner, tol) =
     (check(ccall((:acme_batch_set_resabstol, lib), Cint, (Ptr{Cvoid}, Cdouble), r.h, tol)); tol)

@@ -7,6 +7,8 @@
 
 #include <chrono>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -228,6 +230,8 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return 0;
 }
+// the fiber scheduler below is not re-entrant: asynchronous runs (acme_batch_run_async) take turns
+static inline std::mutex *run_mutex() { static std::mutex m; return &m; }
 }  // namespace be
 
 #include "../../acme_jl_amd/csrc/acme_api.inc"

@@ -24,6 +24,8 @@ FS = 44100
 #   RTOL_TIGHT bound when both sides run with set_resabstol!(1e-13): stopping-test flips are
 #              then harmless and the two must agree to rounding-level
 RTOL = 2e-8
+# the stack the same-Newton-path comparisons run (the model default is the reference's caching stack)
+HS = "HomotopySolver{SimpleSolver}"
 RTOL_SAME = 1e-12
 RTOL_TIGHT = 1e-10
 
@@ -97,27 +99,27 @@ def analytic_cases():
     cases = []
     isc, ise, etac, etae, bf, br = 1e-6, 2e-6, 1.1, 1.0, 100, 10
     for typ in ("npn", "pnp"):
-        m = DiscreteModel(circuits.bjt_test_circuit(typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br), one)
+        m = DiscreteModel(circuits.bjt_test_circuit(typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br), one, HS)
         cases.append((f"bjt_em_{typ}", m, circuits.bjt_test_input(typ)[None]))
         m = DiscreteModel(circuits.bjt_test_circuit(
             typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br, ile=50e-9, ilc=100e-9,
-            etacl=1.2, etael=1.1, vaf=10, var=50, ikf=50e-3, ikr=500e-3), one)
+            etacl=1.2, etael=1.1, vaf=10, var=50, ikf=50e-3, ikr=500e-3), one, HS)
         cases.append((f"bjt_gp_{typ}", m, circuits.bjt_test_input(typ)[None]))
-    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, bf=bf, br=br, vaf=10, var=50), one)
+    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, bf=bf, br=br, vaf=10, var=50), one, HS)
     cases.append(("bjt_early_npn", m, circuits.bjt_test_input("npn")[None]))
-    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, bf=bf, br=br, ikf=50e-3, ikr=500e-3), one)
+    m = DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc, ise=ise, bf=bf, br=br, ikf=50e-3, ikr=500e-3), one, HS)
     cases.append(("bjt_knee_npn", m, circuits.bjt_test_input("npn")[None]))
     vg, vd = np.meshgrid(np.linspace(0, 5, 10), np.linspace(0, 5, 10))
     for typ, pol in (("n", 1), ("p", -1)):
-        m = DiscreteModel(circuits.mosfet_test_circuit(typ, vt=(-1.2454, -0.199, -0.0483), alpha=(0.0205, -0.0017), lam=0.05), one)
+        m = DiscreteModel(circuits.mosfet_test_circuit(typ, vt=(-1.2454, -0.199, -0.0483), alpha=(0.0205, -0.0017), lam=0.05), one, HS)
         cases.append((f"mosfet_{typ}", m, pol * np.stack([vg.ravel(), vd.ravel()])[None]))
-    m = DiscreteModel(circuits.macak_test_circuit(), Fraction(1 / 44100))
+    m = DiscreteModel(circuits.macak_test_circuit(), Fraction(1 / 44100), HS)
     cases.append(("macak", m, np.linspace(-1, 1, 300)[None, None, :]))
-    m = DiscreteModel(circuits.ja_inductor_circuit(), Fraction(1, 44100))
+    m = DiscreteModel(circuits.ja_inductor_circuit(), Fraction(1, 44100), HS)
     u = np.concatenate([np.full(400, 0.1), np.full(400, -0.1), np.zeros(100)])
     cases.append(("ja_inductor", m, np.stack([u, 0.5 * u])[:, None, :]))
     c, _ = circuits.resistor_diode_circuit()
-    cases.append(("resistor_diode", DiscreteModel(c, one), np.zeros((1, 0, 3))))
+    cases.append(("resistor_diode", DiscreteModel(c, one, HS), np.zeros((1, 0, 3))))
     return cases
 
 
@@ -133,7 +135,7 @@ def rare_per_instance_case(n=4):
     for k in range(n):
         c = circuits.ja_inductor_circuit()
         c.elements["L_lin"] = inductor(174e-3 * (1 + 0.1 * (k - 1.5)))
-        models.append(DiscreteModel(c, Fraction(1, 44100)))
+        models.append(DiscreteModel(c, Fraction(1, 44100), HS))
     u1 = np.concatenate([np.full(150, 0.1), np.full(150, -0.1), np.zeros(40)])
     u = np.stack([u1 * (1 + 0.2 * k) for k in range(n)])[:, None, :]
     return models, u

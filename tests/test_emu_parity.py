@@ -450,3 +450,28 @@ def test_emulated_small_shapes_both_run_kernels(emu_lib, name, N, T, monkeypatch
     yref, _ = oracle_run(m, u)
     assert_close(ys["1"], yref, rtol=1e-12)
     assert_close(ys["0"], yref, rtol=1e-12)
+
+
+def test_emulated_multi_device_runner(emu_lib):
+    """One process, several batches started asynchronously (acme_batch_run_async / acme_batch_wait), each on
+    its contiguous instance range and its own slice of u / y: bit-identical to one batch of all instances.
+    (The device ordinal repeats: one emulated device; on a node the ordinals are its GPUs.)"""
+    from acme_jl_amd.runner import AcmeError, ModelRunner, MultiDeviceRunner
+    m = load("superover_fixed")
+    u = np.ascontiguousarray(sweep_inputs("superover_fixed", 7, 240).transpose(0, 2, 1))
+    y1 = ModelRunner(m, 7, lib=emu_lib).run(u, time_major=True)
+    mr = MultiDeviceRunner(m, 7, devices=[0, 0, 0], lib=emu_lib)
+    assert mr.ranges == [(0, 3), (3, 5), (5, 7)]
+    y2 = mr.run(u[:, :100])
+    y2 = np.concatenate([y2, mr.run(u[:, 100:])], axis=1)       # state persists per batch
+    assert np.array_equal(y1, y2)
+    assert mr.report_arrays()["iters_total"].shape == (7,) and mr.get_state()[0].shape == (7, m.nx)
+    # more devices than instances: empty ranges are skipped
+    assert np.array_equal(MultiDeviceRunner(m, 2, devices=[0, 0, 0], lib=emu_lib).run(u[:2]), y1[:2])
+    # a failing run surfaces from wait(), after every run has been joined
+    bad = u.copy()
+    bad[4, 3, 0] = np.inf
+    mr = MultiDeviceRunner(m, 7, devices=[0, 0, 0], lib=emu_lib)
+    with pytest.raises(AcmeError, match="non-finite"):
+        mr.run(bad)
+    assert mr.report_arrays()["first_nonfinite"].tolist() == [-1, -1, -1, -1, 3, -1, -1]

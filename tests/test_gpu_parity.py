@@ -517,3 +517,24 @@ def test_plain_c_client_reproduces_the_doctest(hip_lib):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "doctest vector reproduced" in out.stdout
+
+
+@pytest.mark.gpu
+def test_multi_device_runner_single_process(hip_lib):
+    """The multi-GPU path of a host without torch.distributed (what julia/ACMEHip.jl's MultiBatchRunner
+    does): one process, one batch per device ordinal, runs started with acme_batch_run_async and joined
+    with acme_batch_wait, each on its slice of the caller's host buffers.  The test box has one GPU, so
+    the ordinal repeats (three concurrent batches on device 0); results are bit-identical to one batch."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner, MultiDeviceRunner
+    m = load("superover_var", CachingHomotopySolver)
+    N, T = 96, 4500                    # host runs of 4096+ samples go through the time-slice pipeline
+    u = np.ascontiguousarray(sweep_inputs("superover_var", N, T).transpose(0, 2, 1))
+    y1 = ModelRunner(m, N, lib=hip_lib).run(u, time_major=True)
+    mr = MultiDeviceRunner(m, N, devices=[0, 0, 0], lib=hip_lib)
+    y2 = mr.run(u)
+    assert np.array_equal(y1, y2)
+    assert (mr.report_arrays()["n_warn"] == 0).all()
+    ndev = hip_lib.device_count()
+    if ndev > 1:                       # a multi-GPU node: really one batch per GPU
+        assert np.array_equal(MultiDeviceRunner(m, N, lib=hip_lib).run(u), y1)
