@@ -69,6 +69,7 @@ struct KernelEntry {
     const void *fn, *fn_jac, *fn_solve, *fn_lane;
     int lds_shared, lds_per_inst;  // doubles
     int state;                     // doubles of state per instance
+    int cache_lds;                 // LDS doubles per instance of the solution caches (Shape::CACHEI)
     int lds_lane_plain, lds_lane_caching;   // doubles, lane kernel (0: shape not supported by it)
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
@@ -134,6 +135,7 @@ static const std::vector<KernelEntry> &kernel_table() {
                 lane_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                            \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
+                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::CACHEI,                                                \
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
                 &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                        \

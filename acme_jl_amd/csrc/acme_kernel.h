@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "acme_common.h"
+#include "acme_slab_layout.h"
 
 #ifndef ACME_LAMBDA
 #define ACME_LAMBDA __attribute__((always_inline))
@@ -127,8 +128,16 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int ORIGIN = NSUBr * ORIGIN1 + GROUP;
     // solution cache of one sub-problem of one instance.  In LDS: cp[NP][CACHE] | count, head;
     // in HBM the same followed by cz[NN][CACHE] (see acme_common.h)
-    static constexpr int CACHE1 = NP * CACHE + 2;             // LDS doubles per sub-problem
-    static constexpr int CACHEI = NSUBr * CACHE1;             // LDS doubles per instance
+    // LDS: the stored p's (every lookup reads cp[j][lane & 15]: one ds_read_b64 per parameter).  A wave's
+    // 32-lane read groups hold two instances, each reading 128 contiguous bytes -- half a bank row -- so
+    // two instances must sit an ODD multiple of 128 bytes apart (CACHEI = 16 mod 32 doubles); with the two
+    // counters (count, head) in between, neighbours overlapped in 4 banks (round 2: 2-way conflicts on
+    // every lookup read).  Single-sub-problem shapes keep the counters in the spare word of the report
+    // scratch instead (META_SCR); the others keep them behind the p's and pad.
+    static constexpr bool META_SCR = NSUBr == 1;
+    static constexpr int CACHEPM = NP * CACHE + 2;            // HBM: p's and the two counters of a sub-problem
+    static constexpr int CACHE1 = NP * CACHE + (META_SCR ? 0 : 2);          // LDS doubles per sub-problem
+    static constexpr int CACHEI = ((NSUBr * CACHE1 + 15) / 32) * 32 + 16;   // LDS doubles per instance
     static constexpr int CACHE1H = (NP + NN) * CACHE + 2;     // HBM doubles per sub-problem
     static constexpr int CACHEIH = NSUBr * CACHE1H;           // HBM doubles per instance
     // the solution caches sit at the end of the block's LDS and are only allocated (and touched) when
@@ -282,20 +291,22 @@ template <int NN> struct RowLU {
     // the lanes whose multiplier exceeded PIVOT_THRESHOLD (or that got a non-finite result):
     // if the calling instance's bits are set the result is discarded and the caller redoes the
     // job after a partially pivoted factorisation (factor) has told it the pivot order.
-    // STORE: the lanes with `keep` record the elimination -- slab[k * OS] = minus this row's
-    // multiplier of step k (0 in the pivot's own lane), slab[NN * OS] = 1/pivot of the row -- so that
-    // the same linear map can later be applied to another right-hand side (apply_stored): that is
-    // all the solver needs of the factorisation at its extrapolation origin.
+    // STORE: the lanes with `keep` RECORD the elimination in their entry of the origin slab -- slot k = minus
+    // this row's multiplier of step k (0 in the pivot's own lane), slot NN = 1/pivot of the row -- so that the
+    // same linear map can later be applied to another right-hand side (apply_stored): that is all the
+    // solver needs of the factorisation at its extrapolation origin.  Written as 16-byte pairs
+    // (ds_write_b128; slot s of the entry sits at slab[SH::oslot(s)]) in ONE predicated region at the end:
+    // a store per step costs an exec save / restore each, and 8-byte stores at the entries' 16-byte stride
+    // are 2-way bank conflicts.  An odd slot count (NN even) leaves 1/pivot over: returned in dinv_out, the
+    // caller stores it with the next slot.
     // GJHEAD / SAFE0: see Shape.
-    // (slot s of the slab sits at slab[SLOT(s)]: Shape::oslot)
     template <int NC, bool STORE, class SH, bool GJHEAD, bool SAFE0>
     static ACME_DEV unsigned long long solve_inplace(double (&a)[NN > 0 ? NN : 1], double &b,
-                                                     double (&c)[NC > 0 ? NC : 1], double *slab, bool keep) {
+                                                     double (&c)[NC > 0 ? NC : 1], double *slab, bool keep,
+                                                     double &dinv_out) {
         unsigned long long viol = 0;
         double dinv = 1.0;   // reciprocal of this lane's pivot
-        // STORE: the multipliers wait in registers and go to the slab in ONE predicated region at the end
-        // (a store per step costs an exec save / restore each -- and two v_readlane when the mask is spilled)
-        double rec[STORE ? NN : 1];
+        double rec[STORE ? NN + 1 : 1];
         unsigned long long pivlanes = rows4(1ull);   // lanes holding the pivot row of step k (lig == k)
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
@@ -333,10 +344,13 @@ template <int NN> struct RowLU {
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
         if constexpr (STORE) {
-            if (keep) {
-                sfor<0, NN>([&](auto kc) ACME_LAMBDA { slab[SH::oslot(decltype(kc)::value)] = rec[decltype(kc)::value]; });
-                slab[SH::oslot(NN)] = dinv;
-            }
+            rec[NN] = dinv;
+            dinv_out = dinv;
+            if (keep)
+                sfor<0, (NN + 1) / 2>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = 2 * decltype(kc)::value;
+                    wv::st2(&slab[SH::oslot(k)], rec[k], rec[k + 1]);
+                });
         }
         // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
         viol |= wv::ballot(!(b * 0.0 == 0.0));
@@ -614,12 +628,15 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     int *lds_rowi = (int *)(lds_rowc + NSUB * S::ROWC_L * GROUP);                  // [NSUB][ROWI*16]
     double *lds_scr = lds_rowc + NSUB * (S::ROWC_L * GROUP + S::ROWI_L * GROUP);
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
-    double *const ojp0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + S::OPOS * (grp * NN + lig);
+    // this lane's entry in the wave's origin slab: MULT shapes read / write it as 16-byte pairs, at positions
+    // chosen so that neither the ds_read_b128 nor the ds_write_b128 lane groups collide (acme_slab_layout.h)
+    double *const ojp0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN +
+                         (S::MULT ? 2 * (int)SLAB_POS[NN][lane] : grp * NN + lig);
     double *const cache0 = lds_scr + INST_PER_BLOCK * S::SCRATCH + WAVES_PER_BLOCK * S::ORIGIN + gib * S::CACHEI;
     // context of the sub-problem being solved (switched by enter_sub)
     double *ojp = ojp0;            // origin's J^-1 * Jp, row lig: [j * OS]
     double *cch = cache0;          // solution cache of the current sub-problem: stored p's (LDS)
-    double *czg = A.cache + (valid ? inst : 0) * S::CACHEIH + S::CACHE1;   // ... and stored z's (HBM)
+    double *czg = A.cache + (valid ? inst : 0) * S::CACHEIH + S::CACHEPM;  // ... and stored z's (HBM)
     const double *rowc_s = lds_rowc;
     const int *rowi_s = lds_rowi;
     {   // cooperative load of the model image(s) and the row tables
@@ -653,6 +670,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     const double *Ms = M + L.sub0;                                // current sub-problem block
     double *ubuf = lds_scr + gib * S::SCRATCH;
     double *ybuf = ubuf + S::UBUF;
+    double *const meta_scr = ybuf + S::YBUF + RW_WORDS;      // the word after the report (Shape::RBUF = RW_WORDS + 1)
+    static_assert(S::RBUF > RW_WORDS, "a spare word for the cache counters");
 
     // zero this instance's scratch once: with a padded shape (nu_io < NU) some u-tile entries
     // are read but never written
@@ -660,11 +679,15 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // ... and this wave's origin slabs: a linearisation that fails before anything was recorded
     // must leave a harmless (zero) extrapolation behind, not whatever the LDS held
     for (int i = lane; i < S::ORIGIN; i += 64) lds_scr[INST_PER_BLOCK * S::SCRATCH + wave * S::ORIGIN + i] = 0.0;
+    wv::wave_fence();      // (the cache counters below land in the scratch that has just been zeroed)
     // the solution caches live in HBM between launches
     if (A.solver == SOLVER_CACHING_HOMOTOPY && valid)
         for (int s = 0; s < S::NSUBr; ++s)
-            for (int i = lig; i < S::CACHE1; i += GROUP)
-                cache0[s * S::CACHE1 + i] = A.cache[inst * S::CACHEIH + s * S::CACHE1H + i];
+            for (int i = lig; i < S::CACHEPM; i += GROUP) {
+                const double v = A.cache[inst * S::CACHEIH + s * S::CACHE1H + i];
+                if (i < NP * CACHE || !S::META_SCR) cache0[s * S::CACHE1 + i] = v;
+                else if (i == NP * CACHE) meta_scr[0] = v;   // (count, head), two ints moved as one double
+            }
     wv::wave_fence();
 
     // Which residual row (equation) this lane evaluates.  It starts as the host's row-order
@@ -975,18 +998,19 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             unsigned long long viol;
             double none[1] = {0.0};
             double jp[NPr];
+            double dinv = 0.0;       // (MULT, NN even: the slot left over by the recorded elimination's pairs)
             dz = res;
             const bool recording = wv::ballot(want) != 0ull;
             if (recording) {
                 if constexpr (S::MULT) {
-                    viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN));
+                    viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN), dinv);
                 } else {       // the columns of Jp ride along: jp <- J^-1 Jp
                     calc_jp(jp);
-                    viol = LU::template solve_inplace<NP, false, S, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false);
+                    viol = LU::template solve_inplace<NP, false, S, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false, dinv);
                 }
                 ACME_T(TB_GJP);
             } else {
-                viol = LU::template solve_inplace<0, false, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, false);
+                viol = LU::template solve_inplace<0, false, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, false, dinv);
                 ACME_T(TB_GJ0);
             }
             viol &= wv::ballot(act || force);   // the other instances' results are not used
@@ -1000,10 +1024,19 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             if (recording) {
                 if (S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want && !mine) : (want && !mine && lig < NN)) {   // per-lane predicated LDS stores
                     if constexpr (S::MULT) {
-                        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
-                            constexpr int t = decltype(tc_)::value;
-                            ojp[S::oslot(S::OS_TV + t)] = tv[t];
-                            ojp[S::oslot(S::OS_PF + t)] = pf[t];
+                        // the rest of the entry -- the row's Jq non-zeros and pfull entries -- as 16-byte pairs
+                        // too (the multipliers and 1/pivot went in at the end of the elimination)
+                        sfor<(NN + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
+                            constexpr int c = 2 * decltype(cc)::value;
+                            auto slotv = [&](auto sc) ACME_LAMBDA -> double {
+                                constexpr int sl = decltype(sc)::value;
+                                if constexpr (sl == NN) return dinv;
+                                else if constexpr (sl < S::OS_TV + NT) return tv[sl - S::OS_TV];
+                                else if constexpr (sl < S::OS_PF + NT) return pf[sl - S::OS_PF];
+                                else return 0.0;
+                            };
+                            wv::st2(&ojp[S::oslot(c)], slotv(std::integral_constant<int, c>{}),
+                                    slotv(std::integral_constant<int, c + 1>{}));
                         });
                     } else {
                         sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
@@ -1028,7 +1061,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         rowi_s = lds_rowi + s * ROWI * GROUP;
         ojp = ojp0 + s * S::ORIGIN1;
         cch = cache0 + s * S::CACHE1;
-        czg = A.cache + (valid ? inst : 0) * S::CACHEIH + s * S::CACHE1H + S::CACHE1;
+        czg = A.cache + (valid ? inst : 0) * S::CACHEIH + s * S::CACHE1H + S::CACHEPM;
         lp = lps[s];
         lz = lzs[s];
         rowid = rowids[s];
@@ -1122,7 +1155,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     const bool caching = A.solver == SOLVER_CACHING_HOMOTOPY;
     auto cached_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
         double *cp = cch, *cz = czg;
-        int *meta = reinterpret_cast<int *>(cch + NP * CACHE);   // count, head
+        int *meta = S::META_SCR ? reinterpret_cast<int *>(meta_scr) : reinterpret_cast<int *>(cch + NP * CACHE);   // count, head
         bool reorig = stale != 0;   // (lp, lz) not linearised (in this row order): launch start, ..., or new origin below
         if (caching) {
             const int count = meta[0];
@@ -1214,7 +1247,8 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 }
                 calc_jp(jp);
                 dz = res;
-                const unsigned long long viol = LU::template solve_inplace<NP, false, S, false, true>(a, dz, jp, ojp, false);
+                double dinv;
+                const unsigned long long viol = LU::template solve_inplace<NP, false, S, false, true>(a, dz, jp, ojp, false, dinv);
                 mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
                 if (viol != 0ull && phase == 0) {
                     relearn = mine;
@@ -1571,8 +1605,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         });
         if (A.solver == SOLVER_CACHING_HOMOTOPY)
             for (int s = 0; s < S::NSUBr; ++s)
-                for (int i = lig; i < S::CACHE1; i += GROUP)
-                    A.cache[inst * S::CACHEIH + s * S::CACHE1H + i] = cache0[s * S::CACHE1 + i];
+                for (int i = lig; i < S::CACHEPM; i += GROUP)
+                    A.cache[inst * S::CACHEIH + s * S::CACHE1H + i] =
+                        (i < NP * CACHE || !S::META_SCR) ? cache0[s * S::CACHE1 + i] : (i == NP * CACHE ? meta_scr[0] : 0.0);
         if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
     }
 }

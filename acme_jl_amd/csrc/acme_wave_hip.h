@@ -214,6 +214,12 @@ ACME_DEV pair_t ld2(const double *p) {
     return pair_t{v.x, v.y};
 }
 
+// ... and the matching 16-byte store (ds_write_b128)
+ACME_DEV void st2(double *p, double lo, double hi) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<d2_t *>(__builtin_assume_aligned(p, 16)) = d2_t{lo, hi};
+}
+
 // scheduling fence: nothing is moved across (used to keep a batch of DPP broadcasts ahead of
 // the FMAs that consume them: a dependent dpp->fma pair costs ~17 cycles, batched ~9)
 ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

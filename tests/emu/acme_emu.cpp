@@ -118,7 +118,7 @@ void run_block(int bid, void (*entry)(void *), void *arg) {
 struct KernelEntry {
     Dims d;
     const void *fn, *fn_jac, *fn_solve, *fn_lane;
-    int lds_shared, lds_per_inst, state;
+    int lds_shared, lds_per_inst, state, cache_lds;
     int lds_lane_plain, lds_lane_caching;
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
@@ -174,6 +174,7 @@ static const std::vector<KernelEntry> &kernel_table() {
     KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, nullptr, nullptr,   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
                 Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
+                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::CACHEI,                                                \
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
                 lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
                 &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 0>,                                       \

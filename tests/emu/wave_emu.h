@@ -248,6 +248,7 @@ ACME_DEV ExpTab load_exp_tab() {
 template <class T> ACME_DEV const T *uniform_ro(const T *p) { return p; }
 struct pair_t { double lo, hi; };
 ACME_DEV pair_t ld2(const double *p) { return pair_t{p[0], p[1]}; }
+ACME_DEV void st2(double *p, double lo, double hi) { p[0] = lo; p[1] = hi; }
 ACME_DEV void sched_fence() {}
 ACME_DEV void lds_add(long long *p, long long v) { *p += v; }
 ACME_DEV void lds_max(long long *p, long long v) { if (v > *p) *p = v; }
