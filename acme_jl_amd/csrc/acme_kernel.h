@@ -32,6 +32,10 @@
 #ifndef ACME_LAMBDA
 #define ACME_LAMBDA __attribute__((always_inline))
 #endif
+// branch-layout hints: the rare paths (pivot re-learning, cache hits, failures, the solver-plugin mode of the
+// run kernel) out of the fall-through path -- a taken branch costs a wave an instruction-buffer refill
+#define ACME_RARE(x) __builtin_expect(!!(x), 0)
+#define ACME_USUAL(x) __builtin_expect(!!(x), 1)
 #ifndef ACME_DBG  // debug trace hook, only ever defined by the CPU wave emulator
 #define ACME_DBG(...)
 #endif
@@ -109,8 +113,9 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     //           small shapes, never on the big one -- tools/dpp_hazard_check.py proves which):  big +1 % without
     static constexpr bool FUSE = MULT, GJHEAD = MULT, SAFE0 = !MULT;
     // solve(solver, p) (acme_batch_solve) as a kernel of its own (wave_main MODE_SOLVE), which takes its
-    // pointers and branches out of the run kernel: small shapes +1 .. +4 %, the big one -1.5 % (it keeps both in one)
-    static constexpr bool SOLVE_SPLIT = !MULT;
+    // pointers and branches out of the run kernel: small shapes +1 .. +4 %; the big one lost 1.5 % in round 2
+    // and gains 1.6 % now that the run kernel's rare paths are laid out of line (round 3)
+    static constexpr bool SOLVE_SPLIT = true;
     // constant lane predicates as literals of the scalar AND (and_rows): small shapes only
     static constexpr bool LITROWS = !MULT;
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
@@ -308,6 +313,11 @@ template <int NN> struct RowLU {
         double dinv = 1.0;   // reciprocal of this lane's pivot
         double rec[STORE ? NN + 1 : 1];
         unsigned long long pivlanes = rows4(1ull);   // lanes holding the pivot row of step k (lig == k)
+        // GJHEAD: the largest |multiplier| this row has seen so far (vmx) and -- frozen when the row itself
+        // became the pivot row -- the largest it saw as a row BELOW the pivot (frz): the one the threshold is
+        // about.  Two vector instructions per step, inside the fused step head, instead of a compare into a
+        // scalar pair, two masking s_and_b32 with literals and an s_or_b64 (28 code bytes -> 12): +2.6 %
+        double vmx = 0.0, frz = 0.0;
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
             // a[k] was written by the first fused operation of step k-1; NN-k-1 more of them, the
@@ -321,19 +331,20 @@ template <int NN> struct RowLU {
             if constexpr (GJHEAD) {
                 // pivot broadcast, reciprocal, minus the multiplier of every other row (0 for the pivot
                 // row itself, which notes 1/pivot in dinv) as one fused statement
-                wv::gj_step_head<k, !far_enough>(a[k], dinv, pivlanes, nlm);
+                wv::gj_step_head<k, !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz);
             } else {
                 const double piv = wv::bcast16_ordered<k, !far_enough>(a[k]);
                 const double inv = wv::recip(piv);
                 dinv = lig_eq<k>() ? inv : dinv;
                 nlm = lig_eq<k>() ? 0.0 : a[k] * -inv;
             }
-            const unsigned long long big = wv::ballot(fabs(nlm) > PIVOT_THRESHOLD);
+            unsigned long long big = 0;
+            if constexpr (!GJHEAD) big = wv::ballot(fabs(nlm) > PIVOT_THRESHOLD);
             if constexpr (STORE) {
                 rec[k] = nlm;
             }
             // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
-            viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
+            if constexpr (!GJHEAD) viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
             constexpr bool safe0 = SAFE0 && k == 0;
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
                 wv::fmac_bcast_self<k, safe0>(a[decltype(jc)::value], nlm);
@@ -353,7 +364,8 @@ template <int NN> struct RowLU {
                 });
         }
         // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
-        viol |= wv::ballot(!(b * 0.0 == 0.0));
+        if constexpr (GJHEAD) viol = wv::ballot(frz > PIVOT_THRESHOLD || !(b * 0.0 == 0.0));
+        else viol |= wv::ballot(!(b * 0.0 == 0.0));
         return viol;
     }
 
@@ -710,6 +722,11 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     };
     load_rowdesc();
     const bool has_bjt = A.has_bjt != 0;
+    // The Newton loop's two wave-uniform parameters in VECTOR registers: as scalars they are part of an
+    // 8-register kernel-argument tuple that the allocator spills and reloads whole -- 16 v_readlane per
+    // Newton iteration to look at these two.
+    const double tol_v = wv::keep(A.tol);
+    const int maxiter_v = wv::keepi(A.maxiter);
     ExpTabV etv;
     if constexpr (S::EXPV) {
         const wv::ExpTab t0 = wv::load_exp_tab();
@@ -779,8 +796,6 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         if constexpr (!S::FUSE) {
             sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
             wv::sched_fence();
-        } else {
-            wv::dpp_wait();      // p may be fresh from the homotopy bookkeeping
         }
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
@@ -800,11 +815,14 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + grow]; });
             }
             if constexpr (q0_in_pad) acc = pe[NP];
-            sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (!S::FUSE) acc = fma(pe[j], pb[j], acc);
-                else wv::fmac_bcast<j>(acc, p, pe[j]);
-            });
+            if constexpr (S::FUSE) {       // one statement per term; the first one waits for p (DPP hazard)
+                wv::fmac_bcast_chain<NP, t == 0>(acc, p, pe);
+            } else {
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    acc = fma(pe[j], pb[j], acc);
+                });
+            }
             pf[t] = acc;
             wv::sched_fence();   // bound the number of LDS loads in flight (register pressure)
         });
@@ -850,13 +868,9 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             // z_j reaches the lanes through the DPP operand of the multiply-add; zz is the iterate
             // the caller updated a few instructions before
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
-            wv::dpp_wait();
-            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {      // one statement per term; the first one waits for zz
                 constexpr int t = decltype(tc_)::value;
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    wv::fmac_bcast<j>(e[t], zz, fqv[t][j]);
-                });
+                wv::fmac_bcast_chain<NN, t == 0>(e[t], zz, fqv[t]);
             });
         }
         ACME_T2(TB_E1);
@@ -877,7 +891,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 urc[2 * p + 1] = v.hi;
             });
             const double sA = urc[0], sB = urc[1];
-            if (has_bjt) {                                            // sA/sB = 0: exp(0) = 1
+            if (ACME_USUAL(has_bjt)) {                                // sA/sB = 0: exp(0) = 1
                 exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
             } else {
                 // (big shape: this path -- models without a BJT -- keeps the scalar table; on the register
@@ -976,7 +990,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             phase = wv::opaque(phase);
             finite = evaluate(zz);
             ACME_T(TB_EVAL);
-            if (phase == 1) {
+            if (ACME_RARE(phase == 1)) {
                 // only the instances that tripped the threshold change their row order: what an
                 // instance computes must not depend on which other instances share its wave
                 int orig;        // (local: nothing of it lives across the loops)
@@ -992,7 +1006,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             }
             // only the boolean is needed, so no max-reduction -- one compare and a ballot; a NaN
             // residual counts as not small
-            const unsigned long long big = wv::ballot(!(fabs(res) < A.tol)) & rows4((1ull << NN) - 1ull);
+            const unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4((1ull << NN) - 1ull);
             small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
             const bool want = force || (act && finite && small);
             unsigned long long viol;
@@ -1015,7 +1029,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             }
             viol &= wv::ballot(act || force);   // the other instances' results are not used
             const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
-            if (viol != 0ull && phase == 0) {
+            if (ACME_RARE(viol != 0ull && phase == 0)) {
                 relearn_i = mine ? 1 : 0;
                 phase = 1;
                 continue;
@@ -1133,7 +1147,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             // or singular (src/solvers.jl:203,219-224); `small` is false for a NaN / inf residual
             nf = stop_bad ? (small ? (nf | 2) : (nf & ~2)) : nf;
             nf = want ? (nf | 4) : nf;
-            nf = (step && its < A.maxiter) ? (nf | 1) : nf;
+            nf = (step && its < maxiter_v) ? (nf | 1) : nf;
             fl = wv::keepi(nf);
             ACME_T(TB_GLUE);
         }
@@ -1183,7 +1197,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             const unsigned long long bal = wv::ballot(d == m);
             const int idx = wv::ffs32((int)((bal >> (grp * GROUP)) & 0xFFFFull)) - 1;   // first nearest entry
             const bool hit = need && count > 0 && m < best;
-            if (wv::ballot(hit)) {
+            if (ACME_RARE(wv::ballot(hit))) {
                 const int e = hit ? idx : 0;
                 const double cpl = cp[(lig < NP ? lig : 0) * CACHE + e];
                 const double czl = (valid && caching) ? cz[e * NN + (lig < NN ? lig : 0)] : 0.0;   // HBM, one line
@@ -1192,7 +1206,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
             }
             reorig = reorig || hit;
         }
-        if (wv::ballot(reorig)) {
+        if (ACME_RARE(wv::ballot(reorig))) {
             set_p(lp);
             bool f0, k0, s0;
             double d0;
@@ -1201,7 +1215,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
         const bool c = base_solve(target, need, its);
         if (caching) {
             const bool keep = need && c && its > 5;
-            if (wv::ballot(keep)) {
+            if (ACME_RARE(wv::ballot(keep))) {
                 const int count = meta[0], head = meta[1];
                 wv::wave_fence();
                 if (keep) {
@@ -1279,9 +1293,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     wv::wave_fence();
 
     // ---- time loop ----------------------------------------------------------------------
-    // (the big shapes keep ONE kernel for both, told apart at run time by A.p_in: splitting them changed
-    // nothing but the register allocation of the hot kernel, for the worse -- -1.5 % on the headline)
-    const bool solve_mode = S::SOLVE_SPLIT ? MODE == MODE_SOLVE : A.p_in != nullptr;
+    constexpr bool solve_mode = MODE == MODE_SOLVE;
     const long long T = solve_mode ? 1 : A.T;
     const int nu_io = A.nu_io, ny_io = A.ny_io;
     // u tile: fetched for chunk 0 before the loop and for chunk c+1 at the end of the LAST sample of
@@ -1367,15 +1379,18 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 } else {
                     sfor<0, NX + NU>([&](auto cc) ACME_LAMBDA { dqe[decltype(cc)::value] = Ms[L.pq(decltype(cc)::value, 0, NP, NX) + lig]; });
                 }
-                sfor<0, NX>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    if constexpr (!S::FUSE) {
+                if constexpr (S::FUSE) {       // x: last sample's update
+                    sfor<0, NXS>([&](auto sc) ACME_LAMBDA {
+                        constexpr int xs = decltype(sc)::value;
+                        wv::fmac_bcast_chain<(NX - xs * GROUP < GROUP ? NX - xs * GROUP : GROUP), true, xs * GROUP>(p, x[xs], dqe);
+                    });
+                } else {
+                    sfor<0, NX>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
                         double xj = wv::bcast16<j % GROUP>(x[j / GROUP]);
                         p = fma(dqe[j], xj, p);
-                    } else {
-                        wv::fmac_bcast<j % GROUP>(p, x[j / GROUP], dqe[j]);   // x: last sample's update
-                    }
-                });
+                    });
+                }
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
                     p = fma(dqe[NX + k], us[k], p);
@@ -1385,8 +1400,12 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                     sfor<0, NN>([&](auto jc) ACME_LAMBDA {
                         constexpr int j = decltype(jc)::value;
                         if constexpr (!S::FUSE) p = fma(Ms[L.fqprev + (sp * NN + j) * NP + lig], wv::bcast16<j>(zs[sp]), p);
-                        else wv::fmac_bcast<j>(p, zs[sp], Ms[L.fqprev + (sp * NN + j) * NP + lig]);
                     });
+                    if constexpr (S::FUSE) {
+                        double fp[NNr];
+                        sfor<0, NN>([&](auto jc) ACME_LAMBDA { fp[decltype(jc)::value] = Ms[L.fqprev + (sp * NN + decltype(jc)::value) * NP + lig]; });
+                        wv::fmac_bcast_chain<NN, true>(p, zs[sp], fp);
+                    }
                 });
                 if (solve_mode) p = (valid && lig < A.np_io) ? A.p_in[inst * A.np_io + lig] : 0.0;
                 // solve(::HomotopySolver, p) (src/solvers.jl:268-296) as a per-instance
@@ -1403,7 +1422,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                     bool c = cached_solve(target, need, its);
                     its_sample += need ? its : 0;
                     int nh = need ? ((hf & ~2) | (c ? 2 : 0)) : hf;
-                    if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c))) {
+                    if (ACME_USUAL(A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c)))) {
                         nh &= ~1;
                     } else {
                         bool direct = need && mode == 0;
@@ -1438,7 +1457,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 } else {
                     // convergence policy of step! (src/ACME.jl:688-694)
                     bool failed = alive && !conv;
-                    if (wv::ballot(failed)) {
+                    if (ACME_RARE(wv::ballot(failed))) {
                         unsigned long long nf = S::LITROWS ? wv::ballot(!(z * 0.0 == 0.0)) & rows4((1ull << NN) - 1ull)
                                                            : wv::ballot(lig < NN && !(z * 0.0 == 0.0));
                         bool zfinite = ((nf >> (grp * GROUP)) & 0xFFFFull) == 0ull;
@@ -1485,23 +1504,28 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                     sfor<0, NLC>([&](auto cc) ACME_LAMBDA { w[decltype(cc)::value] = M[L.lin(decltype(cc)::value, 0, NX, NU) + lig]; });
                 }
                 double acc = w[0];
-                if constexpr (S::FUSE) wv::dpp_wait();    // zs[] was selected just above
-                sfor<0, NX>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    if constexpr (!S::FUSE) acc = fma(w[1 + j], wv::bcast16<j>(x[0]), acc);
-                    else wv::fmac_bcast<j>(acc, x[0], w[1 + j]);
-                });
+                if constexpr (S::FUSE) {
+                    wv::fmac_bcast_chain<NX, false, 1>(acc, x[0], w);
+                } else {
+                    sfor<0, NX>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        acc = fma(w[1 + j], wv::bcast16<j>(x[0]), acc);
+                    });
+                }
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA {
                     constexpr int k = decltype(kc)::value;
                     acc = fma(w[1 + NX + k], us[k], acc);
                 });
                 sfor<0, S::NSUB>([&](auto sc) ACME_LAMBDA {
                     constexpr int s = decltype(sc)::value;
-                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                        constexpr int j = decltype(jc)::value;
-                        if constexpr (!S::FUSE) acc = fma(w[1 + NX + NU + s * NN + j], wv::bcast16<j>(zs[s]), acc);
-                        else wv::fmac_bcast<j>(acc, zs[s], w[1 + NX + NU + s * NN + j]);
-                    });
+                    if constexpr (S::FUSE) {       // (zs[] was selected just above: the statement waits)
+                        wv::fmac_bcast_chain<NN, true, 1 + NX + NU + s * NN>(acc, zs[s], w);
+                    } else {
+                        sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                            constexpr int j = decltype(jc)::value;
+                            acc = fma(w[1 + NX + NU + s * NN + j], wv::bcast16<j>(zs[s]), acc);
+                        });
+                    }
                 });
                 if (NY > 0 && lig >= NX && lig < NX + NY) ybuf[m * NY + lig - NX] = live ? acc : (double)NAN;
                 x[0] = sel(S::LITROWS ? and_rows<(1ull << NX) - 1ull, true>(live) : (live && lig < NX), acc, x[0]);
@@ -1567,7 +1591,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 });
             }
             }
-            if (refill) {     // next u tile: this sample's y/x update was the last reader of the old one
+            if (ACME_RARE(refill)) {     // next u tile: this sample's y/x update was the last reader of the old one
                 fetch_u(n0 + S::CH);
                 stage_u();
             }

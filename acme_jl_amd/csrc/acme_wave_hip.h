@@ -57,6 +57,63 @@ template <int K> ACME_DEV void fmac_bcast(double &acc, double src, double mul) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
         : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
 }
+// A whole chain  acc += sum_j (lane j of src's row) * mul[j],  j = 0 .. N-1,  as ONE asm statement.  The
+// compiler assumes that a value written by inline asm has the dst-forwarding hazard (gfx940+) and puts an
+// s_nop between any asm statement and a consumer of its result: with one statement per multiply-add that
+// is a wait state after EVERY v_fmac_f64_dpp of a chain (each consumes the accumulator of the one before)
+// -- ~100 s_nop per sample on the headline shape.  The hardware needs none: the accumulator is an ordinary
+// VALU operand, only `src` is read through DPP, and it is not written inside the chain.  WAIT: two wait
+// states first (src may have been produced by the two preceding VALU instructions).
+#define ACME_FBS(j) "v_fmac_f64_dpp %[acc], %[src], %[m" #j "] row_newbcast:%[k" #j "] row_mask:0xf bank_mask:0xf\n\t"
+#define ACME_FBI(j) [m##j] "v"(mul[OFF + K0 + j]), [k##j] "n"(K0 + j)
+#define ACME_FBS_1 ACME_FBS(0)
+#define ACME_FBI_1 ACME_FBI(0)
+#define ACME_FBS_2 ACME_FBS_1 ACME_FBS(1)
+#define ACME_FBI_2 ACME_FBI_1, ACME_FBI(1)
+#define ACME_FBS_3 ACME_FBS_2 ACME_FBS(2)
+#define ACME_FBI_3 ACME_FBI_2, ACME_FBI(2)
+#define ACME_FBS_4 ACME_FBS_3 ACME_FBS(3)
+#define ACME_FBI_4 ACME_FBI_3, ACME_FBI(3)
+#define ACME_FBS_5 ACME_FBS_4 ACME_FBS(4)
+#define ACME_FBI_5 ACME_FBI_4, ACME_FBI(4)
+#define ACME_FBS_6 ACME_FBS_5 ACME_FBS(5)
+#define ACME_FBI_6 ACME_FBI_5, ACME_FBI(5)
+#define ACME_FBS_7 ACME_FBS_6 ACME_FBS(6)
+#define ACME_FBI_7 ACME_FBI_6, ACME_FBI(6)
+#define ACME_FBS_8 ACME_FBS_7 ACME_FBS(7)
+#define ACME_FBI_8 ACME_FBI_7, ACME_FBI(7)
+#define ACME_FBS_9 ACME_FBS_8 ACME_FBS(8)
+#define ACME_FBI_9 ACME_FBI_8, ACME_FBI(8)
+#define ACME_FBS_10 ACME_FBS_9 ACME_FBS(9)
+#define ACME_FBI_10 ACME_FBI_9, ACME_FBI(9)
+#define ACME_FBS_11 ACME_FBS_10 ACME_FBS(10)
+#define ACME_FBI_11 ACME_FBI_10, ACME_FBI(10)
+#define ACME_FBS_12 ACME_FBS_11 ACME_FBS(11)
+#define ACME_FBI_12 ACME_FBI_11, ACME_FBI(11)
+#define ACME_FBS_13 ACME_FBS_12 ACME_FBS(12)
+#define ACME_FBI_13 ACME_FBI_12, ACME_FBI(12)
+#define ACME_FB_CASE(n)                                                                                   \
+    if constexpr (CNT == n) {                                                                             \
+        if (WAIT) asm("s_nop 1\n\t" ACME_FBS_##n : [acc] "+v"(acc) : [src] "v"(src), ACME_FBI_##n);       \
+        else asm(ACME_FBS_##n : [acc] "+v"(acc) : [src] "v"(src), ACME_FBI_##n);                          \
+    }
+// CNT (<= 13: the operand limit of an asm statement) multiply-adds for lanes K0 .. K0 + CNT - 1
+template <int K0, int CNT, bool WAIT, int OFF, int M> ACME_DEV void fmac_bcast_seg(double &acc, double src, const double (&mul)[M]) {
+    static_assert(CNT >= 1 && CNT <= 13 && M >= OFF + K0 + CNT, "");
+    ACME_FB_CASE(1) ACME_FB_CASE(2) ACME_FB_CASE(3) ACME_FB_CASE(4) ACME_FB_CASE(5) ACME_FB_CASE(6) ACME_FB_CASE(7)
+    ACME_FB_CASE(8) ACME_FB_CASE(9) ACME_FB_CASE(10) ACME_FB_CASE(11) ACME_FB_CASE(12) ACME_FB_CASE(13)
+}
+template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(double &acc, double src, const double (&mul)[M]) {
+    static_assert(N >= 1 && N <= 16, "one DPP row");
+    if constexpr (N <= 13) {
+        fmac_bcast_seg<0, N, WAIT, OFF>(acc, src, mul);
+    } else {
+        fmac_bcast_seg<0, 13, WAIT, OFF>(acc, src, mul);
+        fmac_bcast_seg<13, N - 13, false, OFF>(acc, src, mul);
+    }
+}
+#undef ACME_FB_CASE
+
 // two wait states before a run of fmac_bcast statements whose source may have just been produced
 ACME_DEV void dpp_wait() { asm volatile("s_nop 1"); }
 // Pivot-lane bookkeeping of one elimination step, for the lanes of `mask` only (a wave-uniform
@@ -86,7 +143,7 @@ ACME_DEV unsigned long long mask_shl1(unsigned long long m) {
 // between the transcendental v_rcp_f64 and its first use; EXEC is only written by SALU
 // instructions, which neither DPP nor VALU instructions have to wait for.
 template <int K, bool SAFE>
-ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm) {
+ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz) {
     double piv, inv, e;
     unsigned long long sv;
 #define ACME_GJ_HEAD_BODY                                                                          \
@@ -100,17 +157,19 @@ ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes
         "s_and_saveexec_b64 %[sv], %[m]\n\t"                                                     \
         "v_mov_b64 %[dinv], %[inv]\n\t"                                                          \
         "v_mov_b64 %[nlm], 0\n\t"                                                                \
+        "v_mov_b64 %[frz], %[vmx]\n\t"                                                           \
         "s_mov_b64 exec, %[sv]\n\t"                                                              \
-        "s_lshl_b64 %[m], %[m], 1"
+        "s_lshl_b64 %[m], %[m], 1\n\t"                                                           \
+        "v_max_f64 %[vmx], %[vmx], |%[nlm]|"
     if (SAFE)
         asm volatile("s_nop 1\n\t" ACME_GJ_HEAD_BODY
                      : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),
-                       [sv] "=&s"(sv), [m] "+s"(pivlanes)
+                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz)
                      : [ak] "v"(ak), [k] "n"(K) : "scc");
     else
         asm volatile(ACME_GJ_HEAD_BODY
                      : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),
-                       [sv] "=&s"(sv), [m] "+s"(pivlanes)
+                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz)
                      : [ak] "v"(ak), [k] "n"(K) : "scc");
 #undef ACME_GJ_HEAD_BODY
 }

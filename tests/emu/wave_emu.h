@@ -175,6 +175,10 @@ template <int K> ACME_DEV int bcast16(int v) {
 template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mul) { acc = fma(bcast16<K>(acc), mul, acc); }
 template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) { return bcast16<K>(v); }
 template <int K> ACME_DEV void fmac_bcast(double &acc, double src, double mul) { acc = fma(bcast16<K>(src), mul, acc); }
+template <int I, int N, int OFF, int M> ACME_DEV void fmac_bcast_chain_(double &acc, double src, const double (&mul)[M]) {
+    if constexpr (I < N) { fmac_bcast<I>(acc, src, mul[OFF + I]); fmac_bcast_chain_<I + 1, N, OFF, M>(acc, src, mul); }
+}
+template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(double &acc, double src, const double (&mul)[M]) { fmac_bcast_chain_<0, N, OFF, M>(acc, src, mul); }
 ACME_DEV void dpp_wait() {}
 ACME_DEV bool lanes(unsigned long long mask);
 ACME_DEV void pivot_lane_moves(unsigned long long mask, double &dinv, double inv, double &nlm) {
@@ -183,12 +187,13 @@ ACME_DEV void pivot_lane_moves(unsigned long long mask, double &dinv, double inv
 ACME_DEV unsigned long long mask_shl1(unsigned long long m) { return m << 1; }
 ACME_DEV double recip(double d);
 template <int K, bool SAFE>
-ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm) {
+ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz) {
     const double piv = bcast16<K>(ak);
     const double inv = recip(piv);
     nlm = ak * -inv;
-    if (lanes(pivlanes)) { dinv = inv; nlm = 0.0; }
+    if (lanes(pivlanes)) { dinv = inv; nlm = 0.0; frz = vmx; }
     pivlanes <<= 1;
+    vmx = fmax(vmx, fabs(nlm));      // (v_max_f64: a NaN multiplier is ignored here; the result check catches it)
 }
 template <int R> ACME_DEV double ror16(double v) {
     int lane = tid() & 63;

@@ -7,7 +7,8 @@ OUT=$ROOT/gpurun_out/$tag; mkdir -p "$OUT"
 export PYTHONPATH=$ROOT; cd /tmp; export TMPDIR=/tmp
 WARM=${WARMUP:-3}; STEPS=${STEPS:-3}
 GROUPS_=("SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
-         "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR")
+         "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+         "SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_SMEM SQ_INST_CYCLES_SALU")
 for so in $ROOT/build_variants/*.so; do
   name=$(basename $so .so); i=0
   for grp in "${GROUPS_[@]}"; do
