@@ -15,43 +15,10 @@
 #include <vector>
 
 #include "../../include/acme_hip.h"
-#include "acme_wave_hip.h"
-#include "acme_kernel.h"
-#include "acme_lane_kernel.h"
+#include "acme_kernels.h"
 #include "acme_pack.h"
 
 using namespace acme;
-
-// ------------------------------------------------------------------------------------------
-// kernels: one instantiation per shape of acme_shapes.h
-// ------------------------------------------------------------------------------------------
-template <class S>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_run_kernel(KArgs A) {
-    extern __shared__ double acme_lds[];
-    wave_main<S>(A, acme_lds);
-}
-
-// the small companion kernel: get_extrapolation_jacobian for every instance (wave_main MODE_JAC)
-template <class S>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_jac_kernel(KArgs A) {
-    extern __shared__ double acme_lds[];
-    wave_main<S, MODE_JAC>(A, acme_lds);
-}
-
-// ... and solve(solver, p), once per instance (wave_main MODE_SOLVE): the solver-plugin contract
-template <class S>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_solve_kernel(KArgs A) {
-    extern __shared__ double acme_lds[];
-    wave_main<S, MODE_SOLVE>(A, acme_lds);
-}
-
-// run! for small models, one lane per instance (acme_lane_kernel.h): one wave per SIMD is all these
-// batches offer, so the kernel is built for the shortest dependent chain per sample, not for occupancy
-template <class S>
-__global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
-    extern __shared__ double acme_lds[];
-    lane_main<S>(A, acme_lds);
-}
 
 // LDS budgets the performance of the BASELINE workloads rests on (a CU has 160 KB: two blocks -- two waves per
 // SIMD -- need 80 KB each, solution caches included)
@@ -66,48 +33,14 @@ static_assert(sizeof(double) * (Shape<7, 14, 5, 11, 1, 1, 0, 1>::lds_doubles(tru
 
 struct KernelEntry {
     Dims d;
-    const void *fn, *fn_jac, *fn_solve, *fn_lane;
-    int lds_shared, lds_per_inst;  // doubles
+    KernelFns lds, low;            // images / caches in LDS; the LOW-LDS variants (null where Shape::HAS_LOW is false)
+    const void *fn_lane;
+    int lds_shared, lds_per_inst, lds_low;  // doubles
     int state;                     // doubles of state per instance
     int cache_lds;                 // LDS doubles per instance of the solution caches (Shape::CACHEI)
     int lds_lane_plain, lds_lane_caching;   // doubles, lane kernel (0: shape not supported by it)
-    int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
-    int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
-    int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
 };
-
-template <class S> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL(acme_run_kernel<S>, dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-    return (int)hipGetLastError();
-}
-
-template <class S> static int launch_jac_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    if constexpr (S::NN > 0) {
-        hipLaunchKernelGGL(acme_jac_kernel<S>, dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-        return (int)hipGetLastError();
-    } else {
-        return (int)hipErrorInvalidValue;      // linear models have no nonlinear solver
-    }
-}
-template <class S> static int launch_solve_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    if constexpr (S::NN > 0 && !S::SOLVE_SPLIT) {
-        return launch_shape<S>(A, grid, lds_bytes, st);      // (A.p_in != nullptr tells the run kernel)
-    } else if constexpr (S::NN > 0) {
-        hipLaunchKernelGGL(acme_solve_kernel<S>, dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-        return (int)hipGetLastError();
-    } else {
-        return (int)hipErrorInvalidValue;
-    }
-}
-template <class S> static const void *solve_fn() {
-    if constexpr (S::NN > 0 && S::SOLVE_SPLIT) return (const void *)acme_solve_kernel<S>;
-    else return nullptr;
-}
-template <class S> static const void *jac_fn() {
-    if constexpr (S::NN > 0) return (const void *)acme_jac_kernel<S>;
-    else return nullptr;
-}
 
 template <class S> static int launch_lane_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
     if constexpr (LaneShape<S>::supported) {
@@ -125,26 +58,22 @@ template <class S> static int lane_lds(bool caching) {
     if constexpr (LaneShape<S>::supported) return LaneShape<S>::lds_doubles(caching);
     else return 0;
 }
+template <class S> static KernelEntry make_entry(int index) {
+    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB},
+                       make_fns<S, false>(), S::HAS_LOW ? acme_low_fns(index) : KernelFns{},
+                       lane_fn<S>(), S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE,
+                       S::CACHEI, lane_lds<S>(false), lane_lds<S>(true), &launch_lane_shape<S>};
+}
 
 static const std::vector<KernelEntry> &kernel_table() {
-    static const std::vector<KernelEntry> t = {
-#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, (const void *)acme_run_kernel<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>, \
-                jac_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                             \
-                solve_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                           \
-                lane_fn<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),                                            \
-                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
-                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
-                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::CACHEI,                                                \
-                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
-                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
-                &launch_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                        \
-                &launch_jac_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                    \
-                &launch_solve_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>,                                  \
-                &launch_lane_shape<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>},
+    static const std::vector<KernelEntry> t = [] {
+        std::vector<KernelEntry> v;
+        int index = 0;
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub) v.push_back(make_entry<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(index++));
         ACME_SHAPES(ACME_X)
 #undef ACME_X
-    };
+        return v;
+    }();
     return t;
 }
 

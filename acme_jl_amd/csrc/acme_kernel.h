@@ -151,6 +151,20 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
         return (per_instance ? INST_PER_BLOCK * IMGN : L.total) + NSUBr * (ROWC_L * GROUP + ROWI_L * GROUP) +
                INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
+    // The LOW-LDS kernel variant (wave_main<S, MODE, true>): for batches whose model images -- 16 private
+    // ones per block, or the shared one plus the solution caches -- do not fit the 160 KB of a CU.  The
+    // image(s) are then READ FROM HBM / L2 where the other variant reads LDS (the kind-by-kind row
+    // constants of the RARE shapes too); scratch, origin slabs and solution caches stay in LDS.  Slower
+    // (every evaluate! waits for global loads), but no model the shape can hold is refused: the
+    // reference derives and runs any model, one by one (src/ACME.jl:150, :650-664).
+    static constexpr bool ROWC_G = RARE;      // LOW: row constants from HBM (same layout there as in LDS)
+    ACME_HD static constexpr int lds_doubles_low() {
+        return NSUBr * ((ROWC_G ? 0 : ROWC_L * GROUP) + ROWI_L * GROUP) + INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
+    }
+    // shapes that can need it: anything that does not fit with private images and caches
+    static constexpr bool HAS_LOW = sizeof(double) * (lds_doubles(true) + INST_PER_BLOCK * CACHEI) > 160 * 1024 ||
+                                    sizeof(double) * (lds_doubles(false) + INST_PER_BLOCK * CACHEI) > 160 * 1024;
+    static_assert(sizeof(double) * (lds_doubles_low() + INST_PER_BLOCK * CACHEI) <= 160 * 1024, "the LOW-LDS variant must always fit");
 };
 
 // compile-time counted loops (indices are template constants: DPP lane selects and
@@ -617,7 +631,7 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, dou
 // get_extrapolation_jacobian(solver) = -(J \ Jp) at its extrapolation origin (src/solvers.jl:198-201),
 // a separate, small kernel so that its extra registers and code stay out of the hot one.
 enum { MODE_RUN = 0, MODE_JAC = 1, MODE_SOLVE = 2 };
-template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, double *lds) {
+template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
     constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT, NSUB = S::NSUBr;
     constexpr int NNr = NN > 0 ? NN : 1, NPr = NP > 0 ? NP : 1, NQSr = NQS > 0 ? NQS : 1,
@@ -636,9 +650,10 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     // ---- LDS carve-up -------------------------------------------------------------------
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));   // the block's dynamic LDS starts at 0
     double *lds_img = lds;
-    double *lds_rowc = lds_img + (per_inst ? INST_PER_BLOCK * S::IMGN : L.total);  // [NSUB][ROWC_L*16]
-    int *lds_rowi = (int *)(lds_rowc + NSUB * S::ROWC_L * GROUP);                  // [NSUB][ROWI*16]
-    double *lds_scr = lds_rowc + NSUB * (S::ROWC_L * GROUP + S::ROWI_L * GROUP);
+    constexpr bool ROWC_G = LOW && S::ROWC_G;        // LOW (Shape::lds_doubles_low): no image in LDS, ...
+    double *lds_rowc = lds_img + (LOW ? 0 : per_inst ? INST_PER_BLOCK * S::IMGN : L.total);   // [NSUB][ROWC_L*16]
+    int *lds_rowi = (int *)(lds_rowc + (ROWC_G ? 0 : NSUB * S::ROWC_L * GROUP));               // [NSUB][ROWI*16]
+    double *lds_scr = reinterpret_cast<double *>(lds_rowi) + NSUB * S::ROWI_L * GROUP;
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
     // this lane's entry in the wave's origin slab: MULT shapes read / write it as 16-byte pairs, at positions
     // chosen so that neither the ds_read_b128 nor the ds_write_b128 lane groups collide (acme_slab_layout.h)
@@ -649,11 +664,13 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     double *ojp = ojp0;            // origin's J^-1 * Jp, row lig: [j * OS]
     double *cch = cache0;          // solution cache of the current sub-problem: stored p's (LDS)
     double *czg = A.cache + (valid ? inst : 0) * S::CACHEIH + S::CACHEPM;  // ... and stored z's (HBM)
-    const double *rowc_s = lds_rowc;
+    const double *rowc_s = ROWC_G ? A.rowc : lds_rowc;
     const int *rowi_s = lds_rowi;
     {   // cooperative load of the model image(s) and the row tables
         const int nthreads = WAVES_PER_BLOCK * 64;
-        if (!per_inst) {
+        if constexpr (LOW) {
+            // nothing to stage: the image(s) are read from HBM
+        } else if (!per_inst) {
             for (int i = tid; i < L.total; i += nthreads) lds_img[i] = A.image[i];
         } else {
             for (int g = 0; g < INST_PER_BLOCK; ++g) {
@@ -663,7 +680,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
                 for (int i = tid; i < S::IMGN; i += nthreads) lds_img[g * S::IMGN + i] = src[S::IMG0 + i];
             }
         }
-        for (int s = 0; s < NSUB; ++s)     // only the constants this shape's row evaluation reads
+        for (int s = 0; s < (ROWC_G ? 0 : NSUB); ++s)     // only the constants this shape's row evaluation reads
             for (int i = tid; i < S::ROWC_L * GROUP; i += nthreads) {
                 if constexpr (S::RCPAIR) {      // i = ((pair * 16 + row) * 2 + half)
                     const int c = (i / (2 * GROUP)) * 2 + (i & 1), row = (i >> 1) & (GROUP - 1);
@@ -677,8 +694,10 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     wv::block_sync();
 
     // this instance's image (a private one: only offsets >= IMG0 are there)
-    const double *M = per_inst ? lds_img + (gib * S::IMGN - S::IMG0) : lds_img;
     const double *Mg = A.image + (per_inst && valid ? inst * A.image_stride : 0);   // ... and in HBM
+    const double *M;
+    if constexpr (LOW) M = Mg;
+    else M = per_inst ? lds_img + (gib * S::IMGN - S::IMG0) : lds_img;
     const double *Ms = M + L.sub0;                                // current sub-problem block
     double *ubuf = lds_scr + gib * S::SCRATCH;
     double *ybuf = ubuf + S::UBUF;
@@ -1071,7 +1090,7 @@ template <class S, int MODE = MODE_RUN> ACME_DEV void wave_main(const KArgs &A, 
     auto enter_sub = [&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         Ms = M + L.sub0 + s * L.sub_stride;
-        rowc_s = lds_rowc + s * S::ROWC_L * GROUP;
+        rowc_s = ROWC_G ? A.rowc + s * ROWC * GROUP : lds_rowc + s * S::ROWC_L * GROUP;
         rowi_s = lds_rowi + s * ROWI * GROUP;
         ojp = ojp0 + s * S::ORIGIN1;
         cch = cache0 + s * S::CACHE1;

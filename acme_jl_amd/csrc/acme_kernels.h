@@ -1,0 +1,82 @@
+// acme_kernels.h -- the __global__ kernels over acme_kernel.h / acme_lane_kernel.h and their launchers,
+// shared by the library's two translation units: acme_hip.hip (every shape, images / caches in LDS) and
+// acme_hip_low.hip (the LOW-LDS variants of the shapes that can need them, Shape::HAS_LOW), which are
+// compiled in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "acme_wave_hip.h"
+#include "acme_kernel.h"
+#include "acme_lane_kernel.h"
+#include "acme_shapes.h"
+
+namespace acme {
+
+// one instantiation per shape of acme_shapes.h (LOW: model images read from HBM, Shape::lds_doubles_low)
+template <class S, bool LOW>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_run_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S, MODE_RUN, LOW>(A, acme_lds);
+}
+
+// the small companion kernel: get_extrapolation_jacobian for every instance (wave_main MODE_JAC)
+template <class S, bool LOW>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_jac_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S, MODE_JAC, LOW>(A, acme_lds);
+}
+
+// ... and solve(solver, p), once per instance (wave_main MODE_SOLVE): the solver-plugin contract
+template <class S, bool LOW>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_solve_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S, MODE_SOLVE, LOW>(A, acme_lds);
+}
+
+// run! for small models, one lane per instance (acme_lane_kernel.h): one wave per SIMD is all these
+// batches offer, so the kernel is built for the shortest dependent chain per sample, not for occupancy
+template <class S>
+__global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    lane_main<S>(A, acme_lds);
+}
+
+// the three 16-lane kernels of one shape in one placement (LDS / LOW): entry points for
+// hipFuncSetAttribute and launchers
+struct KernelFns {
+    const void *fn = nullptr, *fn_jac = nullptr, *fn_solve = nullptr;
+    int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
+    int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
+    int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
+};
+
+template <class S, bool LOW> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((acme_run_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+    return (int)hipGetLastError();
+}
+template <class S, bool LOW> static int launch_jac_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((acme_jac_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+    return (int)hipGetLastError();
+}
+template <class S, bool LOW> static int launch_solve_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((acme_solve_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+    return (int)hipGetLastError();
+}
+template <class S, bool LOW> static KernelFns make_fns() {
+    KernelFns f;
+    f.fn = (const void *)acme_run_kernel<S, LOW>;
+    f.launch = &launch_shape<S, LOW>;
+    if constexpr (S::NN > 0) {       // (linear models have no nonlinear solver)
+        f.fn_jac = (const void *)acme_jac_kernel<S, LOW>;
+        f.fn_solve = (const void *)acme_solve_kernel<S, LOW>;
+        f.launch_jac = &launch_jac_shape<S, LOW>;
+        f.launch_solve = &launch_solve_shape<S, LOW>;
+    }
+    return f;
+}
+
+// defined in acme_hip_low.hip: the LOW-LDS kernels of shape number `index` of ACME_SHAPES (all null for
+// the shapes that never need them)
+KernelFns acme_low_fns(int index);
+
+}  // namespace acme

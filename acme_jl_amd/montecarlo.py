@@ -171,23 +171,16 @@ def _initial_solution_batch(table, fq, q0, nn, device=None):
     ``device``: None -> the numpy restatement above (no GPU needed); else a dict(lib=..., device=...)
     -> all N solves in one batched ``acme_batch_solve`` on the GPU (``analysis.solve_rays``: the
     same homotopy path, walked by the same kernel that later runs the models).
-    Shapes whose per-instance blocks do not fit the LDS fall back to numpy."""
+    (Models whose private blocks do not fit the LDS run in the LOW-LDS kernels: nothing is refused.)"""
     if nn == 0:
         return np.zeros((q0.shape[0], 0))
     if device is not None:
         from .analysis import solve_rays
-        from .runner import AcmeError
-        try:
-            z, conv = solve_rays(table, None, nn, q0.shape[1], q0, fq, lib=device.get("lib"), device=device.get("device"))
-        except AcmeError as e:
-            if "LDS" not in str(e):
-                raise
-            device.setdefault("fallbacks", []).append(str(e))
-        else:
-            if not conv.all():
-                raise RuntimeError("Failed to find initial solution")
-            device["solved"] = device.get("solved", 0) + q0.shape[0]
-            return z
+        z, conv = solve_rays(table, None, nn, q0.shape[1], q0, fq, lib=device.get("lib"), device=device.get("device"))
+        if not conv.all():
+            raise RuntimeError("Failed to find initial solution")
+        device["solved"] = device.get("solved", 0) + q0.shape[0]
+        return z
     z, conv = _BatchHomotopy(table, fq, nn).solve(q0)
     if not conv.all():
         raise RuntimeError("Failed to find initial solution")

@@ -115,14 +115,18 @@ void run_block(int bid, void (*entry)(void *), void *arg) {
 // ------------------------------------------------------------------------------------------
 // kernel table
 // ------------------------------------------------------------------------------------------
+struct KernelFns {
+    const void *fn = nullptr, *fn_jac = nullptr, *fn_solve = nullptr;
+    int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
+    int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
+    int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
+};
 struct KernelEntry {
     Dims d;
-    const void *fn, *fn_jac, *fn_solve, *fn_lane;
-    int lds_shared, lds_per_inst, state, cache_lds;
+    KernelFns lds, low;
+    const void *fn_lane;
+    int lds_shared, lds_per_inst, lds_low, state, cache_lds;
     int lds_lane_plain, lds_lane_caching;
-    int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
-    int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
-    int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
 };
 
@@ -131,35 +135,23 @@ struct LaunchCtx {
     double *lds;
 };
 
-template <class S> static void fiber_entry(void *p) {
+// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel, 3: solve kernel; LOW: the LOW-LDS variant
+template <class S, int KIND, bool LOW> static void fiber_entry(void *p) {
     LaunchCtx *c = (LaunchCtx *)p;
-    wave_main<S>(*c->A, c->lds);
+    if constexpr (KIND == 0) wave_main<S, MODE_RUN, LOW>(*c->A, c->lds);
+    else if constexpr (KIND == 1) { if constexpr (S::NN > 0) wave_main<S, MODE_JAC, LOW>(*c->A, c->lds); }
+    else if constexpr (KIND == 3) { if constexpr (S::NN > 0) wave_main<S, MODE_SOLVE, LOW>(*c->A, c->lds); }
+    else { if constexpr (LaneShape<S>::supported) lane_main<S>(*c->A, c->lds); }
 }
 
-template <class S> static void fiber_entry_jac(void *p) {
-    LaunchCtx *c = (LaunchCtx *)p;
-    if constexpr (S::NN > 0) wave_main<S, MODE_JAC>(*c->A, c->lds);
-}
-
-template <class S> static void fiber_entry_solve(void *p) {
-    LaunchCtx *c = (LaunchCtx *)p;
-    if constexpr (S::NN > 0) wave_main<S, S::SOLVE_SPLIT ? MODE_SOLVE : MODE_RUN>(*c->A, c->lds);
-}
-
-template <class S> static void fiber_entry_lane(void *p) {
-    LaunchCtx *c = (LaunchCtx *)p;
-    if constexpr (LaneShape<S>::supported) lane_main<S>(*c->A, c->lds);
-}
-
-// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel, 3: solve kernel
-template <class S, int KIND> static int launch_any(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
+template <class S, int KIND, bool LOW = false> static int launch_any(const KArgs &A, unsigned grid, size_t lds_bytes, void *) {
     static_assert(emu::BLOCK == LANE_BLOCK && emu::BLOCK == WAVES_PER_BLOCK * 64, "one emulated block = one kernel block");
     std::vector<double> lds(lds_bytes / sizeof(double) + 64);
     LaunchCtx c{&A, lds.data()};
     for (unsigned b = 0; b < grid; ++b) {
         // poison the LDS with NaNs: a kernel reading uninitialised LDS into a result shows up
         for (auto &v : lds) v = std::nan("");
-        emu::run_block((int)b, KIND == 1 ? &fiber_entry_jac<S> : KIND == 2 ? &fiber_entry_lane<S> : KIND == 3 ? &fiber_entry_solve<S> : &fiber_entry<S>, &c);
+        emu::run_block((int)b, &fiber_entry<S, KIND, LOW>, &c);
     }
     return 0;
 }
@@ -167,20 +159,29 @@ template <class S> static int lane_lds(bool caching) {
     if constexpr (LaneShape<S>::supported) return LaneShape<S>::lds_doubles(caching);
     else return 0;
 }
+static int emu_fn_tag;       // (the emulator has no kernel entry points: any non-null value marks "exists")
+template <class S, bool LOW> static KernelFns make_fns() {
+    KernelFns f;
+    if constexpr (LOW && !S::HAS_LOW) return f;
+    f.fn = &emu_fn_tag;
+    f.launch = &launch_any<S, 0, LOW>;
+    if constexpr (S::NN > 0) {
+        f.fn_jac = f.fn_solve = &emu_fn_tag;
+        f.launch_jac = &launch_any<S, 1, LOW>;
+        f.launch_solve = &launch_any<S, 3, LOW>;
+    }
+    return f;
+}
+template <class S> static KernelEntry make_entry() {
+    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB},
+                       make_fns<S, false>(), make_fns<S, true>(), nullptr,
+                       S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
+                       lane_lds<S>(false), lane_lds<S>(true), &launch_any<S, 2>};
+}
 
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
-#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub)                                                              \
-    KernelEntry{Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0}, nullptr, nullptr, nullptr, nullptr,   \
-                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(false),                                   \
-                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::lds_doubles(true), Shape<nn, nq, np, nx, nu, ny, rare, nsub>::STATE,  \
-                Shape<nn, nq, np, nx, nu, ny, rare, nsub>::CACHEI,                                                \
-                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(false),                                      \
-                lane_lds<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(true),                                       \
-                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 0>,                                       \
-                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 1>,                                       \
-                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 3>,                                       \
-                &launch_any<Shape<nn, nq, np, nx, nu, ny, rare, nsub>, 2>},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub) make_entry<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),
         ACME_EMU_SHAPES(ACME_X)
 #undef ACME_X
     };

@@ -475,3 +475,57 @@ def test_emulated_multi_device_runner(emu_lib):
     with pytest.raises(AcmeError, match="non-finite"):
         mr.run(bad)
     assert mr.report_arrays()["first_nonfinite"].tolist() == [-1, -1, -1, -1, 3, -1, -1]
+
+
+def test_emulated_low_lds_variant(emu_lib, monkeypatch):
+    """The LOW-LDS kernels (model images read from HBM instead of LDS; taken when 16 private images, or the
+    shared image next to the solution caches, do not fit a CU's 160 KB) compute exactly what the LDS
+    kernels compute: forced on a batch that would fit (ACME_LOW_LDS=1), bit for bit; run, solve and
+    Jacobian export."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    for name, solver in (("superover_var", None), ("superover_var", CachingHomotopySolver)):
+        m = load(name, solver)
+        u = sweep_inputs(name, 5, 120)
+        out = {}
+        for low in ("0", "1"):
+            monkeypatch.setenv("ACME_LOW_LDS", low)
+            r = ModelRunner(m, 5, lib=emu_lib)
+            y = r.run(u)
+            z, conv, its = r.solve(np.tile(r.get_state()[1][:1], (5, 1)) * 1.01)
+            out[low] = (y, z, its, r.get_extrapolation_jacobian())
+        for a, b in zip(out["0"], out["1"]):
+            assert np.array_equal(a, b)
+
+
+def test_emulated_per_instance_matrices_beyond_lds(emu_lib):
+    """Monte-Carlo component tolerances on the VARIABLE-pot superover (nn = 13: 16 private images are 264 KB,
+    more than a CU's LDS -- refused until round 3): every instance against the oracle run of its own,
+    exactly derived model.  And the reference's default (caching) stack on a decomposed model whose four
+    solution caches do not fit next to the shared image."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    from acme_jl_amd.montecarlo import derive_batch
+    make = lambda value: examples.superover(value=value)     # noqa: E731   (pots as inputs)
+    nominal = {}
+    make(lambda name, v: nominal.setdefault(name, v))
+    rng = np.random.Generator(np.random.PCG64(11))
+    vals = {k: v * (1 + 0.05 * rng.uniform(-1, 1, 3)) for k, v in nominal.items()}
+    batch = derive_batch(make, Fraction(1, 44100), vals, solver="HomotopySolver{SimpleSolver}")
+    u = sweep_inputs("superover_var", 3, 140)
+    r = ModelRunner(batch.model(0), 3, models=batch, lib=emu_lib)
+    assert r.kernel_shape()[:3] == (13, 29, 11)
+    y = r.run(u)
+    for k in range(3):
+        exact = DiscreteModel(make(lambda name, v: float(vals[name][k])), Fraction(1, 44100), "HomotopySolver{SimpleSolver}")
+        yref, _ = oracle_run(exact, u[k:k + 1])
+        assert_close(y[k:k + 1], yref, rtol=1e-9)
+    assert np.abs(y[0] - y[1]).max() > 1e-6
+    mv = _simplified_superover(True, CachingHomotopySolver)          # 4 sub-problems, medium shape
+    uv = sweep_inputs("superover_var", 2, 100)
+    r = ModelRunner(mv, 2, lib=emu_lib)
+    assert r.kernel_shape()[:3] == (8, 24, 8)
+    yref, _ = oracle_run(mv, uv, cache_limit=16)
+    assert_close(r.run(uv), yref)

@@ -538,3 +538,55 @@ def test_multi_device_runner_single_process(hip_lib):
     ndev = hip_lib.device_count()
     if ndev > 1:                       # a multi-GPU node: really one batch per GPU
         assert np.array_equal(MultiDeviceRunner(m, N, lib=hip_lib).run(u), y1)
+
+
+def test_low_lds_kernels(hip_lib, monkeypatch):
+    """The LOW-LDS kernels (images read from HBM instead of LDS) against the LDS kernels, bit for bit, on a batch
+    that fits both ways (ACME_LOW_LDS=1 forces them): run with the caching stack, solve, Jacobian export."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    m = load("superover_var", CachingHomotopySolver)
+    u = sweep_inputs("superover_var", 70, 700)
+    out = {}
+    for low in ("0", "1"):
+        monkeypatch.setenv("ACME_LOW_LDS", low)
+        r = runner(hip_lib, m, 70)
+        y = r.run(u)
+        z, conv, its = r.solve(r.get_state()[1] * 1.01)
+        out[low] = (y, z, its, r.get_extrapolation_jacobian())
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
+def test_monte_carlo_variable_pot_superover(hip_lib):
+    """Per-instance matrices beyond the LDS ceiling: component tolerances on the VARIABLE-pot
+    superover (nn = 13; 16 private images are 264 KB).  Blocks from the structure-replaying front end with the
+    initial solutions taken on the device; spot instances against oracle runs of exactly derived models.  And
+    the reference's default stack on a decomposed model whose caches do not fit next to the image."""
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from acme_jl_amd.montecarlo import derive_batch
+    from acme_jl_amd.runner import ModelRunner
+    from test_emu_parity import _simplified_superover
+    make = lambda value: examples.superover(value=value)     # noqa: E731
+    nominal = {}
+    make(lambda name, v: nominal.setdefault(name, v))
+    rng = np.random.Generator(np.random.PCG64(20250905))
+    N = 40
+    vals = {k: v * (1 + 0.05 * rng.uniform(-1, 1, N)) for k, v in nominal.items()}
+    info = dict(lib=hip_lib)
+    batch = derive_batch(make, Fraction(1, 44100), vals, solver="HomotopySolver{SimpleSolver}", init_on_device=info)
+    assert info.get("solved", 0) >= N and "fallbacks" not in info
+    u = sweep_inputs("superover_var", N, 600)
+    r = ModelRunner(batch.model(0), N, models=batch, lib=hip_lib)
+    assert r.kernel_shape()[:3] == (13, 29, 11)
+    y = r.run(u)
+    for k in (0, 15, 16, 39):
+        exact = DiscreteModel(make(lambda name, v: float(vals[name][k])), Fraction(1, 44100), "HomotopySolver{SimpleSolver}")
+        yref, _ = oracle_run(exact, u[k:k + 1])
+        assert_close(y[k:k + 1], yref, rtol=1e-9)
+    assert np.abs(y[0] - y[1]).max() > 1e-6 and (r.report_arrays()["n_warn"] == 0).all()
+    mv = _simplified_superover(True, CachingHomotopySolver)
+    uv = sweep_inputs("superover_var", 6, 400)
+    yref, _ = oracle_run(mv, uv, cache_limit=16)
+    assert_close(runner(hip_lib, mv, 6).run(uv), yref)

@@ -24,12 +24,22 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
 def disassemble(lib):
+    """disassembly of every gfx950 code object in the library (one offload bundle per translation unit)"""
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
         subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib])
-        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}",
-                               f"--input={fat}", f"--output={co}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", co], text=True)
+        data = open(fat, "rb").read()
+        starts = [m for m in range(len(data)) if data.startswith(magic, m)] if data.count(magic) > 1 else [0]
+        out = []
+        for k, st in enumerate(starts):
+            part = os.path.join(d, f"fat{k}.bin")
+            with open(part, "wb") as fh:
+                fh.write(data[st:starts[k + 1] if k + 1 < len(starts) else len(data)])
+            subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}",
+                                   f"--input={part}", f"--output={co}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            out.append(subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", co], text=True))
+        return "\n".join(out)
 
 
 INS = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]{12}):\s+((?:[0-9A-Fa-f]{8} ?)+)")
