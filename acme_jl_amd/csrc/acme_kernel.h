@@ -101,17 +101,18 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // while np is small (measured on MI355X: replaying gains 9 % at np = 11 / nn = 13 and loses
     // 2 % at 5 / 7, 6 % at 3 / 4, 7 % at 1 / 2, where its nn dependent DPP steps dominate).
     static constexpr bool MULT = NP >= 8;
-    // Three more choices follow the same split (A/B on MI355X, EXPERIMENTS.md): on the big shape,
-    // whose two waves per SIMD compete for issue slots, fewer instructions win; on the small shapes,
-    // whose launches last as long as ONE wave's dependent chains, shorter chains win.
-    //   FUSE    broadcasts of x_j / z_j / p_j fused into the consuming multiply-add (v_fmac_f64_dpp)
-    //           instead of v_mov_b64_dpp + v_fmac_f64:      big +1.7 %, small -1 .. -3.7 %
-    //   GJHEAD  the scalar head of an elimination step as one fused asm statement with the pivot
-    //           lane handled under a narrowed EXEC instead of four v_cndmask:  big +1 %, small -1 .. -3 %
-    //   SAFE0   step 0 of the elimination with the two DPP wait states built into every fused
-    //           operation (the compiler may copy a row register just before it; it does on the
-    //           small shapes, never on the big one -- tools/dpp_hazard_check.py proves which):  big +1 % without
-    static constexpr bool FUSE = MULT, GJHEAD = MULT, SAFE0 = !MULT;
+    // Three more per-shape choices (A/B on MI355X, EXPERIMENTS.md; re-measured in round 3 once the fused
+    // operations had become single asm statements without compiler-inserted wait states):
+    //   FUSE    broadcasts of x_j / z_j / p_j fused into the consuming multiply-add (chains of v_fmac_f64_dpp,
+    //           wv::fmac_bcast_chain) instead of v_mov_b64_dpp + v_fmac_f64: headline +1.7 %, fixed-pot superover
+    //           (np = 5) +1.9 %, birdie (np = 3) -2.5 %
+    //   GJHEAD  the scalar head of an elimination step as one fused asm statement -- pivot lane handled under a
+    //           narrowed EXEC instead of four v_cndmask, threshold test as two vector instructions inside it:
+    //           headline +3.6 %, fixed-pot superover +2.5 %, birdie +1.4 %
+    //   SAFE0   step 0 of the elimination with the two DPP wait states built into every fused operation (the
+    //           compiler may copy a row register just before it; it does on the small shapes, never on the big
+    //           one -- tools/dpp_hazard_check.py proves which): big +1 % without
+    static constexpr bool FUSE = NP >= 5, GJHEAD = NN > 0, SAFE0 = !MULT;
     // solve(solver, p) (acme_batch_solve) as a kernel of its own (wave_main MODE_SOLVE), which takes its
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %; the big one lost 1.5 % in round 2
     // and gains 1.6 % now that the run kernel's rare paths are laid out of line (round 3)
@@ -161,6 +162,11 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     ACME_HD static constexpr int lds_doubles_low() {
         return NSUBr * ((ROWC_G ? 0 : ROWC_L * GROUP) + ROWI_L * GROUP) + INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
+    // Blocks per CU the register budget is cut for (__launch_bounds__): two -- 256 VGPRs per lane -- unless
+    // the shape's LDS footprint lets only ONE block (one wave per SIMD) live on a CU anyway: then the whole
+    // 512-register file is the wave's (the generic 16-unknown shape spilled 435 registers to scratch under
+    // the 256 limit)
+    static constexpr int OCC = sizeof(double) * lds_doubles(false) > 80 * 1024 ? 1 : 2;
     // shapes that can need it: anything that does not fit with private images and caches
     static constexpr bool HAS_LOW = sizeof(double) * (lds_doubles(true) + INST_PER_BLOCK * CACHEI) > 160 * 1024 ||
                                     sizeof(double) * (lds_doubles(false) + INST_PER_BLOCK * CACHEI) > 160 * 1024;

@@ -14,21 +14,21 @@ namespace acme {
 
 // one instantiation per shape of acme_shapes.h (LOW: model images read from HBM, Shape::lds_doubles_low)
 template <class S, bool LOW>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_run_kernel(KArgs A) {
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, S::OCC) void acme_run_kernel(KArgs A) {
     extern __shared__ double acme_lds[];
     wave_main<S, MODE_RUN, LOW>(A, acme_lds);
 }
 
 // the small companion kernel: get_extrapolation_jacobian for every instance (wave_main MODE_JAC)
 template <class S, bool LOW>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_jac_kernel(KArgs A) {
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, S::OCC) void acme_jac_kernel(KArgs A) {
     extern __shared__ double acme_lds[];
     wave_main<S, MODE_JAC, LOW>(A, acme_lds);
 }
 
 // ... and solve(solver, p), once per instance (wave_main MODE_SOLVE): the solver-plugin contract
 template <class S, bool LOW>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2) void acme_solve_kernel(KArgs A) {
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, S::OCC) void acme_solve_kernel(KArgs A) {
     extern __shared__ double acme_lds[];
     wave_main<S, MODE_SOLVE, LOW>(A, acme_lds);
 }

@@ -17,6 +17,9 @@
 #elif defined(ACME_DEV_SHAPES) && ACME_DEV_SHAPES + 0 == 5
 #define ACME_SHAPES(X)                                                                     \
     X( 4,  9,  3,  3, 2, 1, 0, 1)
+#elif defined(ACME_DEV_SHAPES) && ACME_DEV_SHAPES + 0 == 16
+#define ACME_SHAPES(X)                                                                     \
+    X(16, 32, 16, 32, 8, 8, 1, 1)
 #elif defined(ACME_DEV_SHAPES)
 #define ACME_SHAPES(X)                                                                     \
     X(13, 29, 11, 11, 4, 1, 0, 1)

@@ -104,8 +104,9 @@ template <int K0, int CNT, bool WAIT, int OFF, int M> ACME_DEV void fmac_bcast_s
     ACME_FB_CASE(8) ACME_FB_CASE(9) ACME_FB_CASE(10) ACME_FB_CASE(11) ACME_FB_CASE(12) ACME_FB_CASE(13)
 }
 template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(double &acc, double src, const double (&mul)[M]) {
-    static_assert(N >= 1 && N <= 16, "one DPP row");
-    if constexpr (N <= 13) {
+    static_assert(N >= 0 && N <= 16, "one DPP row");
+    if constexpr (N == 0) {
+    } else if constexpr (N <= 13) {
         fmac_bcast_seg<0, N, WAIT, OFF>(acc, src, mul);
     } else {
         fmac_bcast_seg<0, 13, WAIT, OFF>(acc, src, mul);

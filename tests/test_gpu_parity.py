@@ -590,3 +590,39 @@ def test_monte_carlo_variable_pot_superover(hip_lib):
     uv = sweep_inputs("superover_var", 6, 400)
     yref, _ = oracle_run(mv, uv, cache_limit=16)
     assert_close(runner(hip_lib, mv, 6).run(uv), yref)
+
+
+@pytest.mark.parametrize("lane_kernel", ["1", "0"])
+@pytest.mark.parametrize("name,N,T", [("diodeclipper", 300, 2000), ("birdie_fixed", 130, 2000)])
+def test_small_shapes_both_run_kernels(hip_lib, name, N, T, lane_kernel, monkeypatch):
+    """The shapes the lane-per-instance kernel takes by default, under BOTH run kernels (ACME_LANE_KERNEL=0 keeps
+    the 16-lane kernel: the A/B fallback and the code path of acme_batch_solve / the Jacobian export on such
+    batches): each against the oracle on the same Newton paths, default and caching stack."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    monkeypatch.setenv("ACME_LANE_KERNEL", lane_kernel)
+    for solver, limit in ((None, None), (CachingHomotopySolver, 16)):
+        m = load(name, solver)
+        u = sweep_inputs(name, N, T)
+        r = runner(hip_lib, m, N)
+        y = r.run(u)
+        pick = np.linspace(0, N - 1, 12).astype(int)
+        yref, its = oracle_run(m, u[pick], cache_limit=limit)
+        assert_close(y[pick], yref, rtol=RTOL_SAME if solver is None else RTOL)
+        if solver is None:
+            assert r.report_arrays()["iters_total"][pick].tolist() == its.tolist()
+
+
+@pytest.mark.parametrize("lane_kernel", ["1", "0"])
+def test_nonlinear_model_without_inputs(hip_lib, lane_kernel, monkeypatch):
+    """run!(model, zeros(0, T)) on a nonlinear model with a state and no inputs (u == NULL at the C ABI; ADVICE
+    r2: the lane kernel once dereferenced it)."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    monkeypatch.setenv("ACME_LANE_KERNEL", lane_kernel)
+    m = DiscreteModel(circuits.constant_source_clipper(0.8), Fraction(1, 44100), "HomotopySolver{SimpleSolver}")
+    u = np.zeros((70, 0, 64))
+    y = runner(hip_lib, m, 70).run(u)
+    yref, _ = oracle_run(m, u[:1])
+    assert_close(y[:1], yref, rtol=RTOL_SAME)
+    assert np.array_equal(y, np.tile(y[:1], (70, 1, 1))) and 0.6 < y[0, 0, -1] < 0.7
