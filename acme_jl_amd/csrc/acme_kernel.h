@@ -350,8 +350,15 @@ template <int NN> struct RowLU {
             double nlm;                                            // -multiplier of every other row
             if constexpr (GJHEAD) {
                 // pivot broadcast, reciprocal, minus the multiplier of every other row (0 for the pivot
-                // row itself, which notes 1/pivot in dinv) as one fused statement
-                wv::gj_step_head<k, !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz);
+                // row itself, which notes 1/pivot in dinv), threshold bookkeeping AND the row updates
+                //   a[j] -= l * (pivot row's a[j])  (j > k),  b and c[] likewise
+                // as one fused statement (two when there are more than 7 registers to update)
+                constexpr int CNT = NN - 1 - k + 1 + NC;
+                double *rp[CNT];
+                sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA { rp[decltype(jc)::value - k - 1] = &a[decltype(jc)::value]; });
+                rp[NN - 1 - k] = &b;
+                sfor<0, NC>([&](auto jc) ACME_LAMBDA { rp[NN - k + decltype(jc)::value] = &c[decltype(jc)::value]; });
+                wv::gj_step<k, CNT, !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz, rp);
             } else {
                 const double piv = wv::bcast16_ordered<k, !far_enough>(a[k]);
                 const double inv = wv::recip(piv);
@@ -365,12 +372,14 @@ template <int NN> struct RowLU {
             }
             // rows k+1..NN-1 whose multiplier exceeds the pivot threshold (scalar mask arithmetic)
             if constexpr (!GJHEAD) viol = wv::pin(viol | (big & rows4(((1ull << NN) - 1ull) & ~((2ull << k) - 1ull))));
-            constexpr bool safe0 = SAFE0 && k == 0;
-            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
-                wv::fmac_bcast_self<k, safe0>(a[decltype(jc)::value], nlm);
-            });
-            wv::fmac_bcast_self<k, safe0>(b, nlm);
-            sfor<0, NC>([&](auto jc) ACME_LAMBDA { wv::fmac_bcast_self<k, safe0>(c[decltype(jc)::value], nlm); });
+            if constexpr (!GJHEAD) {
+                constexpr bool safe0 = SAFE0 && k == 0;
+                sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
+                    wv::fmac_bcast_self<k, safe0>(a[decltype(jc)::value], nlm);
+                });
+                wv::fmac_bcast_self<k, safe0>(b, nlm);
+                sfor<0, NC>([&](auto jc) ACME_LAMBDA { wv::fmac_bcast_self<k, safe0>(c[decltype(jc)::value], nlm); });
+            }
         });
         b *= dinv;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
@@ -383,9 +392,10 @@ template <int NN> struct RowLU {
                     wv::st2(&slab[SH::oslot(k)], rec[k], rec[k + 1]);
                 });
         }
-        // a zero pivot without a larger candidate (exactly singular A) turns every row into NaN
-        if constexpr (GJHEAD) viol = wv::ballot(frz > PIVOT_THRESHOLD || !(b * 0.0 == 0.0));
-        else viol |= wv::ballot(!(b * 0.0 == 0.0));
+        // a zero pivot without a larger candidate (exactly singular A) or a NaN in A or b turns every row into
+        // NaN; an infinite pivot leaves 1/pivot = 0 behind
+        if constexpr (GJHEAD) viol = wv::ballot(frz > PIVOT_THRESHOLD || !(b * 0.0 == 0.0) || dinv == 0.0);
+        else viol |= wv::ballot(!(b * 0.0 == 0.0) || dinv == 0.0);
         return viol;
     }
 
@@ -938,16 +948,13 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             });
             a[j] = acc;
         });
-        // non-finite anywhere in this instance's res / J ?  (src/solvers.jl:220)  0*x is 0 for
-        // finite x and NaN otherwise; a chain of 4-byte v_fmac (code size matters more here than
-        // the length of the dependency chain).  J = Jq fq with finite constants fq: it is finite when
-        // the row's Jq non-zeros are, short of an overflow of their products with fq -- which turns the
-        // elimination's result non-finite and ends the solve the same way (solve_inplace checks).
-        double chk = res * 0.0;
-        sfor<0, NT>([&](auto tc_) ACME_LAMBDA { chk = fma(tv[decltype(tc_)::value], 0.0, chk); });
-        unsigned long long bad = S::LITROWS ? wv::ballot(!(chk == 0.0)) & rows4((1ull << NN) - 1ull)
-                                            : wv::ballot(lig < NN && !(chk == 0.0));
-        return ((bad >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+        // Non-finite anywhere in this instance's res / J (src/solvers.jl:219-221: solve() returns at once)?  No
+        // test of its own here: a NaN in res or J turns the elimination's result into NaN, an infinite residual
+        // too (inf * 0), an infinite entry of J ends up as a pivot (the pivot search prefers it) whose stored
+        // reciprocal is 0 -- solve_inplace reports all three (`mine`), and the caller stops exactly like the
+        // reference does: hasconverged = (max |res| < tol), which a non-finite residual fails.  (A separate
+        // finiteness ballot cost 9 vector instructions per evaluate!.)
+        return true;
     };
 
     // calc_Jp closure (src/ACME.jl:246-251): Jp row = Jq row * pexp

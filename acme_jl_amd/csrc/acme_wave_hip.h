@@ -175,6 +175,79 @@ ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes
 #undef ACME_GJ_HEAD_BODY
 }
 
+// One WHOLE Gauss-Jordan step as (at most two) asm statements: the step head above followed by the row updates
+//   r[j] += (lane K of r[j]'s row) * nlm      for the CNT registers r[] (the columns right of the pivot, b)
+// Between separate statements the compiler assumes a dst-forwarding hazard and inserts a wait state: two per
+// step with the head and every update a statement of its own.  Operand limit of a statement: 30 -- the head
+// takes 15, every read-modify-write register 2 -- so the first statement carries up to 7 updates, a second
+// one the rest.  DPP hazards: r[j] was last written one whole step ago; SAFE (step 0, and wherever ak is fresh):
+// two wait states at the head of BOTH statements -- the compiler may copy a register just before either.
+#define ACME_FSELF(j) "v_fmac_f64_dpp %[r" #j "], %[r" #j "], %[nlm] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define ACME_RSELF(j) [r##j] "+v"(*rp[O + j])
+#define ACME_FSELF_1 ACME_FSELF(0)
+#define ACME_RSELF_1 ACME_RSELF(0)
+#define ACME_FSELF_2 ACME_FSELF_1 ACME_FSELF(1)
+#define ACME_RSELF_2 ACME_RSELF_1, ACME_RSELF(1)
+#define ACME_FSELF_3 ACME_FSELF_2 ACME_FSELF(2)
+#define ACME_RSELF_3 ACME_RSELF_2, ACME_RSELF(2)
+#define ACME_FSELF_4 ACME_FSELF_3 ACME_FSELF(3)
+#define ACME_RSELF_4 ACME_RSELF_3, ACME_RSELF(3)
+#define ACME_FSELF_5 ACME_FSELF_4 ACME_FSELF(4)
+#define ACME_RSELF_5 ACME_RSELF_4, ACME_RSELF(4)
+#define ACME_FSELF_6 ACME_FSELF_5 ACME_FSELF(5)
+#define ACME_RSELF_6 ACME_RSELF_5, ACME_RSELF(5)
+#define ACME_FSELF_7 ACME_FSELF_6 ACME_FSELF(6)
+#define ACME_RSELF_7 ACME_RSELF_6, ACME_RSELF(6)
+#define ACME_FSELF_8 ACME_FSELF_7 ACME_FSELF(7)
+#define ACME_RSELF_8 ACME_RSELF_7, ACME_RSELF(7)
+#define ACME_FSELF_9 ACME_FSELF_8 ACME_FSELF(8)
+#define ACME_RSELF_9 ACME_RSELF_8, ACME_RSELF(8)
+#define ACME_GJ_HEAD_TEXT                                                                          \
+        "v_mov_b64_dpp %[piv], %[ak] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"          \
+        "v_rcp_f64_e32 %[inv], %[piv]\n\t"                                                       \
+        "s_nop 0\n\t"                                                                            \
+        "v_fma_f64 %[e], -%[piv], %[inv], 1.0\n\t"                                               \
+        "v_fmac_f64_e32 %[e], %[e], %[e]\n\t"                                                    \
+        "v_fmac_f64_e32 %[inv], %[inv], %[e]\n\t"                                                \
+        "v_mul_f64 %[nlm], %[ak], -%[inv]\n\t"                                                   \
+        "s_and_saveexec_b64 %[sv], %[m]\n\t"                                                     \
+        "v_mov_b64 %[dinv], %[inv]\n\t"                                                          \
+        "v_mov_b64 %[nlm], 0\n\t"                                                                \
+        "v_mov_b64 %[frz], %[vmx]\n\t"                                                           \
+        "s_mov_b64 exec, %[sv]\n\t"                                                              \
+        "s_lshl_b64 %[m], %[m], 1\n\t"                                                           \
+        "v_max_f64 %[vmx], %[vmx], |%[nlm]|\n\t"
+#define ACME_GJ_A(n)                                                                                          \
+    if constexpr (NA == n) {                                                                                  \
+        constexpr int O = 0;                                                                                  \
+        if (SAFE) asm volatile("s_nop 1\n\t" ACME_GJ_HEAD_TEXT ACME_FSELF_##n                                  \
+                     : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),  \
+                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz), ACME_RSELF_##n    \
+                     : [ak] "v"(ak), [k] "n"(K) : "scc");                                                      \
+        else asm volatile(ACME_GJ_HEAD_TEXT ACME_FSELF_##n                                                     \
+                     : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),  \
+                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz), ACME_RSELF_##n    \
+                     : [ak] "v"(ak), [k] "n"(K) : "scc");                                                      \
+    }
+#define ACME_GJ_B(n)                                                                                          \
+    if constexpr (CNT - NA == n) {                                                                            \
+        constexpr int O = NA;                                                                                 \
+        if (SAFE) asm volatile("s_nop 1\n\t" ACME_FSELF_##n : ACME_RSELF_##n : [nlm] "v"(nlm), [k] "n"(K));     \
+        else asm volatile(ACME_FSELF_##n : ACME_RSELF_##n : [nlm] "v"(nlm), [k] "n"(K));                      \
+    }
+template <int K, int CNT, bool SAFE>
+ACME_DEV void gj_step(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz, double *const (&rp)[CNT]) {
+    static_assert(CNT >= 1 && CNT <= 16, "");
+    constexpr int NA = CNT < 7 ? CNT : 7;
+    double piv, inv, e;
+    unsigned long long sv;
+    ACME_GJ_A(1) ACME_GJ_A(2) ACME_GJ_A(3) ACME_GJ_A(4) ACME_GJ_A(5) ACME_GJ_A(6) ACME_GJ_A(7)
+    ACME_GJ_B(1) ACME_GJ_B(2) ACME_GJ_B(3) ACME_GJ_B(4) ACME_GJ_B(5) ACME_GJ_B(6) ACME_GJ_B(7) ACME_GJ_B(8) ACME_GJ_B(9)
+}
+#undef ACME_GJ_A
+#undef ACME_GJ_B
+#undef ACME_GJ_HEAD_TEXT
+
 // bcast16<K> as a volatile statement (ordered with the fused operations); SAFE: with the two wait
 // states built in
 template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) {

@@ -128,6 +128,14 @@ def pmc_valu_issue_frac(workload, n, T, n_simd=1024, n_xcd=8):
     return r["sq_insts_valu_per_launch"] / (n_simd * r["grbm_gui_active_per_launch"] / n_xcd / 4.0)
 
 
+def pmc_lds_bank_conflict_frac(workload, n, T):
+    """SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the profiled timed steps (north_star names the counter), or None."""
+    r = pmc_record(workload, n, T)
+    if r is None or not r.get("sq_lds_idx_active_per_launch"):
+        return None
+    return r["sq_lds_bank_conflict_per_launch"] / r["sq_lds_idx_active_per_launch"]
+
+
 def algorithmic_bytes(model, n, T):
     """8*(nu+ny) bytes per instance*sample + per-launch state/model traffic."""
     s = model.subs[0] if model.subs else None
@@ -511,12 +519,13 @@ def main():
                 "fp64_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
                 / (last_ms * 1e-3) / 1e12 if model.subs else None,
                 "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+                "lds_bank_conflict_frac": pmc_lds_bank_conflict_frac(args.workload, n_per_gpu, T),
                 "valu_issue_frac": pmc_valu_issue_frac(args.workload, n_per_gpu, T),
                 "valu_issue_profiled_kernel_ms": (pmc_record(args.workload, n_per_gpu, T) or {}).get("kernel_avg_ms_profiled"),
-                "valu_issue_note": "VALU wave-instructions issued / (1024 SIMDs x cycles / 4), from the committed "
-                                   "rocprofv3 PMC pass of this workload (profiles/pmc_traffic.json; instructions and cycles "
-                                   "are means over the same profiled launches, whose mean duration is "
-                                   "valu_issue_profiled_kernel_ms -- warm-up launches included, hence above kernel_ms); null if none",
+                "valu_issue_note": "VALU wave-instructions issued / (1024 SIMDs x cycles / 4) and LDS bank-conflict cycles / "
+                                   "LDS-active cycles, from the committed rocprofv3 PMC passes of this workload "
+                                   "(profiles/pmc_traffic.json, tools/profile_gpu.sh: means over the dispatches of the TIMED "
+                                   "steps only, whose mean duration is valu_issue_profiled_kernel_ms); null if none",
             },
         }
         if use_dist and not rehearsal:

@@ -195,6 +195,11 @@ ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes
     pivlanes <<= 1;
     vmx = fmax(vmx, fabs(nlm));      // (v_max_f64: a NaN multiplier is ignored here; the result check catches it)
 }
+template <int K, int CNT, bool SAFE>
+ACME_DEV void gj_step(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz, double *const (&rp)[CNT]) {
+    gj_step_head<K, SAFE>(ak, dinv, pivlanes, nlm, vmx, frz);
+    for (int j = 0; j < CNT; ++j) *rp[j] = fma(bcast16<K>(*rp[j]), nlm, *rp[j]);
+}
 template <int R> ACME_DEV double ror16(double v) {
     int lane = tid() & 63;
     // row_ror:R -- lane i receives the value of lane (i - R) mod 16 of its row
