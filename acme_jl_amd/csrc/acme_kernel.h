@@ -1448,33 +1448,50 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 double ha = 0.5, hbest = 0.0, startp = 0.0, target = p;
                 ACME_DBG("sample %lld sub %d lane %d p %.17g x %.17g lp %.17g lz %.17g", n, s, lane, p, x[0], lp, lz);
                 ACME_T(TB_PRE);
-                while (wv::ballot((hf & 1) != 0)) {
+                // The direct attempt first, as straight-line code: it almost always settles the sample, and outside
+                // a loop it needs none of the register copies and flag traffic of a loop head.  The bisection loop --
+                // a second, cold copy of the solver -- runs only when some instance's direct attempt failed.
+                auto hstep = [&](bool need, bool c, int nh) ACME_LAMBDA -> int {     // bookkeeping after one base solve
+                    bool direct = need && mode == 0;
+                    bool homot = need && mode == 1;
+                    bool start = direct && !c;
+                    startp = sel(start, lp, startp);
+                    bool hgood = homot && c;
+                    hbest = sel(hgood, ha, hbest);
+                    double new_a = (ha + hbest) / 2.0;
+                    bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
+                    ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
+                    ha = sel(start, 0.5, ha);
+                    hbest = sel(start, 0.0, hbest);
+                    mode = sel(start, 1, mode);
+                    need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
+                    double pa = startp * (1.0 - ha);
+                    pa = pa + ha * p;
+                    target = sel(need, pa, target);
+                    return need ? (nh | 1) : (nh & ~1);
+                };
+                {
+                    const bool need = alive;
+                    int its;
+                    const bool c = cached_solve(target, need, its);
+                    its_sample = need ? its : 0;
+                    int nh = need ? ((hf & ~2) | (c ? 2 : 0)) : hf;
+                    if (ACME_USUAL(A.solver == SOLVER_SIMPLE || !wv::ballot(need && !c))) {
+                        nh &= ~1;
+                    } else {
+                        nh = hstep(need, c, nh);
+                    }
+                    hf = wv::keepi(nh);
+                    ACME_T(TB_HOMO);
+                }
+                while (ACME_RARE(wv::ballot((hf & 1) != 0))) {
                     bool need = (hf & 1) != 0;
                     int its;
                     bool c = cached_solve(target, need, its);
                     its_sample += need ? its : 0;
                     int nh = need ? ((hf & ~2) | (c ? 2 : 0)) : hf;
-                    if (ACME_USUAL(A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c)))) {
-                        nh &= ~1;
-                    } else {
-                        bool direct = need && mode == 0;
-                        bool homot = need && mode == 1;
-                        bool start = direct && !c;
-                        startp = sel(start, lp, startp);
-                        bool hgood = homot && c;
-                        hbest = sel(hgood, ha, hbest);
-                        double new_a = (ha + hbest) / 2.0;
-                        bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
-                        ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
-                        ha = sel(start, 0.5, ha);
-                        hbest = sel(start, 0.0, hbest);
-                        mode = sel(start, 1, mode);
-                        need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
-                        double pa = startp * (1.0 - ha);
-                        pa = pa + ha * p;
-                        target = sel(need, pa, target);
-                        nh = need ? (nh | 1) : (nh & ~1);
-                    }
+                    if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c))) nh &= ~1;
+                    else nh = hstep(need, c, nh);
                     hf = wv::keepi(nh);
                     ACME_T(TB_HOMO);
                 }

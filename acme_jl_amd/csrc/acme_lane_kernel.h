@@ -377,7 +377,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 idx = c ? e : idx;
             });
             const bool hit = need && idx >= 0;
-            if (wv::ballot(hit)) {
+            if (ACME_RARE(wv::ballot(hit))) {
                 const int e = hit ? idx : 0;
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
@@ -465,32 +465,48 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             int mode = 0, its_sample = 0;
             double ha = 0.5, hbest = 0.0, startp[NPr], target[NPr];
             sfor<0, NP>([&](auto jc) ACME_LAMBDA { target[decltype(jc)::value] = p[decltype(jc)::value]; startp[decltype(jc)::value] = 0.0; });
-            while (wv::ballot(need)) {
+            // The direct attempt first, outside any loop: it almost always settles the sample, and as
+            // straight-line code it costs none of the register copies a loop head needs for everything that
+            // lives across it (the solution cache, the u / y tiles, the origin: ~120 moves per sample as a
+            // loop).  The bisection loop -- a second, cold copy of the solver -- only runs when an instance's
+            // direct attempt failed.
+            auto hstep = [&](bool c) ACME_LAMBDA {          // bookkeeping of solve(::HomotopySolver) after one base solve
+                const bool direct = need && mode == 0, homot = need && mode == 1;
+                const bool start = direct && !c;
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { startp[decltype(jc)::value] = sel(start, lp[decltype(jc)::value], startp[decltype(jc)::value]); });
+                const bool hgood = homot && c;
+                hbest = sel(hgood, ha, hbest);
+                const double new_a = (ha + hbest) / 2.0;
+                const bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
+                ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
+                ha = sel(start, 0.5, ha);
+                hbest = sel(start, 0.0, hbest);
+                mode = sel(start, 1, mode);
+                need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    double pa = startp[j] * (1.0 - ha);
+                    pa = pa + ha * p[j];
+                    target[j] = sel(need, pa, target[j]);
+                });
+            };
+            {
                 int its;
                 const bool c = cached_solve(target, need, its);
-                its_sample += need ? its : 0;
+                its_sample = need ? its : 0;
                 conv = need ? c : conv;
-                if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c))) {
+                if (ACME_USUAL(A.solver == SOLVER_SIMPLE || !wv::ballot(need && !c))) {
                     need = false;
                 } else {
-                    const bool direct = need && mode == 0, homot = need && mode == 1;
-                    const bool start = direct && !c;
-                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { startp[decltype(jc)::value] = sel(start, lp[decltype(jc)::value], startp[decltype(jc)::value]); });
-                    const bool hgood = homot && c;
-                    hbest = sel(hgood, ha, hbest);
-                    const double new_a = (ha + hbest) / 2.0;
-                    const bool hbreak = homot && !c && !(hbest < new_a && new_a < ha);
-                    ha = sel(hgood, 1.0, sel(homot && !c, new_a, ha));
-                    ha = sel(start, 0.5, ha);
-                    hbest = sel(start, 0.0, hbest);
-                    mode = sel(start, 1, mode);
-                    need = need && !(direct && c) && !hbreak && !(homot && hbest >= 1.0);
-                    sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-                        constexpr int j = decltype(jc)::value;
-                        double pa = startp[j] * (1.0 - ha);
-                        pa = pa + ha * p[j];
-                        target[j] = sel(need, pa, target[j]);
-                    });
+                    hstep(c);
+                    while (wv::ballot(need)) {
+                        int its2;
+                        const bool c2 = cached_solve(target, need, its2);
+                        its_sample += need ? its2 : 0;
+                        conv = need ? c2 : conv;
+                        if (A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c2))) need = false;
+                        else hstep(c2);
+                    }
                 }
             }
             // convergence policy of step! (src/ACME.jl:688-694)
