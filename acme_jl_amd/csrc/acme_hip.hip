@@ -42,27 +42,19 @@ struct KernelEntry {
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
 };
 
-template <class S> static int launch_lane_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    if constexpr (LaneShape<S>::supported) {
-        hipLaunchKernelGGL(acme_lane_kernel<S>, dim3(grid), dim3(LANE_BLOCK), lds_bytes, st, A);
-        return (int)hipGetLastError();
-    } else {
-        return (int)hipErrorInvalidValue;
-    }
-}
-template <class S> static const void *lane_fn() {
-    if constexpr (LaneShape<S>::supported) return (const void *)acme_lane_kernel<S>;
-    else return nullptr;
-}
 template <class S> static int lane_lds(bool caching) {
     if constexpr (LaneShape<S>::supported) return LaneShape<S>::lds_doubles(caching);
     else return 0;
 }
+// (this translation unit instantiates no kernel: the entry points come from the parts)
 template <class S> static KernelEntry make_entry(int index) {
-    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB},
-                       make_fns<S, false>(), S::HAS_LOW ? acme_low_fns(index) : KernelFns{},
-                       lane_fn<S>(), S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE,
-                       S::CACHEI, lane_lds<S>(false), lane_lds<S>(true), &launch_lane_shape<S>};
+    ShapeFns f;
+    if (!(acme_shape_fns_part0(index, &f) || acme_shape_fns_part1(index, &f) || acme_shape_fns_part2(index, &f) ||
+          acme_shape_fns_part3(index, &f)))
+        abort();
+    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB}, f.lds, f.low, f.fn_lane,
+                       S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
+                       lane_lds<S>(false), lane_lds<S>(true), f.launch_lane};
 }
 
 static const std::vector<KernelEntry> &kernel_table() {

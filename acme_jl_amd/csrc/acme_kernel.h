@@ -1005,48 +1005,33 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // elimination (their multipliers and 1/pivot), the row's Jq non-zeros and its pfull entries in
     // the origin slab (set_extrapolation_origin, src/solvers.jl:191-196: the reference keeps the
     // factors and Jp there; Jp (p' - p) = Jq (pexp p' - pexp p) needs only Jq and pfull).  If the
-    // in-place pivots were not the maxima (a few % of the calls) the retry loop evaluates again,
-    // runs the reference's partially pivoted LU to learn the pivot order, lets the lanes adopt it,
-    // evaluates in the new order and eliminates again.  evaluate / pivot_order each have ONE call
-    // site (code size, registers); `phase` is opaque so that the optimiser does not clone the
-    // body per phase.  finite: res and J finite; ok: J non-singular; small: |res| < tol.
+    // in-place pivots were not the maxima (a few % of the calls) a rare, out-of-line block evaluates
+    // again, runs the reference's partially pivoted LU to learn the pivot order, lets the lanes adopt
+    // it, evaluates in the new order and eliminates again.  (Rounds 1-2 ran the three stages as one
+    // loop over an opaque `phase` so that evaluate / pivot_order had ONE call site each; the usual
+    // pass as straight-line code saves the loop head's register copies and two branches per Newton
+    // iteration.)  finite: res and J finite; ok: J non-singular; small: |res| < tol.
     // `stale`: the slab no longer describes the origin (lp, lz) in the lanes' current order -- an
     // instance changed its row order without storing a new origin, or a recorded elimination was
     // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
     int stale = 1;       // (an integer in a vector register, like the loop flags of base_solve)
     auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
-        int okf = 1;     // `ok`, and below `relearn`: carried across the phases as integers in vector registers
-        int phase = 0;   // 0: first try   1: learn the pivot order   2: retry in the new order
-        int relearn_i = 0;      // this instance tripped the threshold in phase 0
-        for (;;) {
-            phase = wv::opaque(phase);
-            finite = evaluate(zz);
-            ACME_T(TB_EVAL);
-            if (ACME_RARE(phase == 1)) {
-                // only the instances that tripped the threshold change their row order: what an
-                // instance computes must not depend on which other instances share its wave
-                int orig;        // (local: nothing of it lives across the loops)
-                const bool relearn = relearn_i != 0;
-                const bool okp = LU::pivot_order(a, orig, lig, grp);
-                okf = relearn ? (okp ? 1 : 0) : 1;
-                orig = relearn ? orig : lig;
-                adopt(orig);
-                if constexpr (S::MULT) stale = relearn ? 1 : stale;   // the recorded elimination is per row order
-                phase = 2;
-                ACME_T(TB_PIVOT);
-                continue;
-            }
+        int okf = 1;     // `ok`: carried as an integer in a vector register
+        bool want, recording, mine;
+        double jp[NPr];
+        double dinv = 0.0;       // (MULT, NN even: the slot left over by the recorded elimination's pairs)
+        // the elimination on the latest evaluate!; returns the lanes that tripped the pivot threshold (or got a
+        // non-finite result), restricted to the instances whose result is used
+        auto eliminate = [&]() ACME_LAMBDA -> unsigned long long {
             // only the boolean is needed, so no max-reduction -- one compare and a ballot; a NaN
             // residual counts as not small
             const unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4((1ull << NN) - 1ull);
             small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
-            const bool want = force || (act && finite && small);
+            want = force || (act && finite && small);
             unsigned long long viol;
             double none[1] = {0.0};
-            double jp[NPr];
-            double dinv = 0.0;       // (MULT, NN even: the slot left over by the recorded elimination's pairs)
             dz = res;
-            const bool recording = wv::ballot(want) != 0ull;
+            recording = wv::ballot(want) != 0ull;
             if (recording) {
                 if constexpr (S::MULT) {
                     viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN), dinv);
@@ -1060,42 +1045,56 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 ACME_T(TB_GJ0);
             }
             viol &= wv::ballot(act || force);   // the other instances' results are not used
-            const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
-            if (ACME_RARE(viol != 0ull && phase == 0)) {
-                relearn_i = mine ? 1 : 0;
-                phase = 1;
-                continue;
-            }
-            okf = mine ? 0 : okf;
-            if (recording) {
-                if (S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want && !mine) : (want && !mine && lig < NN)) {   // per-lane predicated LDS stores
-                    if constexpr (S::MULT) {
-                        // the rest of the entry -- the row's Jq non-zeros and pfull entries -- as 16-byte pairs
-                        // too (the multipliers and 1/pivot went in at the end of the elimination)
-                        sfor<(NN + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
-                            constexpr int c = 2 * decltype(cc)::value;
-                            auto slotv = [&](auto sc) ACME_LAMBDA -> double {
-                                constexpr int sl = decltype(sc)::value;
-                                if constexpr (sl == NN) return dinv;
-                                else if constexpr (sl < S::OS_TV + NT) return tv[sl - S::OS_TV];
-                                else if constexpr (sl < S::OS_PF + NT) return pf[sl - S::OS_PF];
-                                else return 0.0;
-                            };
-                            wv::st2(&ojp[S::oslot(c)], slotv(std::integral_constant<int, c>{}),
-                                    slotv(std::integral_constant<int, c + 1>{}));
-                        });
-                    } else {
-                        sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
-                    }
-                }
-                // MULT: recorded and kept -> the slab is the origin-to-be; recorded but unusable -> it
-                // is nothing.  Otherwise the slab is only written when the result is kept.
-                if constexpr (S::MULT) stale = want ? (mine ? 1 : 0) : stale;
-                else stale = (want && !mine) ? 0 : stale;
-            }
-            ACME_T(TB_STORE);
-            break;
+            mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
+            return viol;
+        };
+        // The usual pass, as straight-line code (no phase variable, no loop head to copy registers at) ...
+        finite = evaluate(zz);
+        ACME_T(TB_EVAL);
+        if (ACME_RARE(eliminate() != 0ull)) {
+            // ... and the rare one: some instance of the wave has to re-learn its pivot order.  Only the
+            // instances that tripped the threshold change their row order: what an instance computes must
+            // not depend on which other instances share its wave.
+            const bool relearn = mine;
+            (void)evaluate(zz);                  // J once more (the elimination has consumed it)
+            int orig;
+            const bool okp = LU::pivot_order(a, orig, lig, grp);
+            okf = relearn ? (okp ? 1 : 0) : 1;
+            orig = relearn ? orig : lig;
+            adopt(orig);
+            if constexpr (S::MULT) stale = relearn ? 1 : stale;   // the recorded elimination is per row order
+            ACME_T(TB_PIVOT);
+            finite = evaluate(zz);               // ... in the new row order
+            (void)eliminate();
         }
+        okf = mine ? 0 : okf;
+        if (recording) {
+            if (S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want && !mine) : (want && !mine && lig < NN)) {   // per-lane predicated LDS stores
+                if constexpr (S::MULT) {
+                    // the rest of the entry -- the row's Jq non-zeros and pfull entries -- as 16-byte pairs
+                    // too (the multipliers and 1/pivot went in at the end of the elimination)
+                    sfor<(NN + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
+                        constexpr int c = 2 * decltype(cc)::value;
+                        auto slotv = [&](auto sc) ACME_LAMBDA -> double {
+                            constexpr int sl = decltype(sc)::value;
+                            if constexpr (sl == NN) return dinv;
+                            else if constexpr (sl < S::OS_TV + NT) return tv[sl - S::OS_TV];
+                            else if constexpr (sl < S::OS_PF + NT) return pf[sl - S::OS_PF];
+                            else return 0.0;
+                        };
+                        wv::st2(&ojp[S::oslot(c)], slotv(std::integral_constant<int, c>{}),
+                                slotv(std::integral_constant<int, c + 1>{}));
+                    });
+                } else {
+                    sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[decltype(jc)::value * OS] = jp[decltype(jc)::value]; });
+                }
+            }
+            // MULT: recorded and kept -> the slab is the origin-to-be; recorded but unusable -> it
+            // is nothing.  Otherwise the slab is only written when the result is kept.
+            if constexpr (S::MULT) stale = want ? (mine ? 1 : 0) : stale;
+            else stale = (want && !mine) ? 0 : stale;
+        }
+        ACME_T(TB_STORE);
         ok = okf != 0;
     };
 

@@ -1,7 +1,6 @@
 // acme_kernels.h -- the __global__ kernels over acme_kernel.h / acme_lane_kernel.h and their launchers,
-// shared by the library's two translation units: acme_hip.hip (every shape, images / caches in LDS) and
-// acme_hip_low.hip (the LOW-LDS variants of the shapes that can need them, Shape::HAS_LOW), which are
-// compiled in parallel.
+// shared by the library's translation units: acme_hip.hip (the C ABI, no kernels) and acme_hip_part<k>.hip
+// (the kernels of every ACME_NPARTS-th shape), which are compiled in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -75,8 +74,37 @@ template <class S, bool LOW> static KernelFns make_fns() {
     return f;
 }
 
-// defined in acme_hip_low.hip: the LOW-LDS kernels of shape number `index` of ACME_SHAPES (all null for
-// the shapes that never need them)
-KernelFns acme_low_fns(int index);
+// everything the host needs of one shape's kernels: the 16-lane kernels with the images in LDS and (where the
+// shape can need them, Shape::HAS_LOW) their LOW-LDS variants, and the lane-per-instance run kernel
+struct ShapeFns {
+    KernelFns lds, low;
+    const void *fn_lane = nullptr;
+    int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
+};
+template <class S> static int launch_lane_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    if constexpr (LaneShape<S>::supported) {
+        hipLaunchKernelGGL(acme_lane_kernel<S>, dim3(grid), dim3(LANE_BLOCK), lds_bytes, st, A);
+        return (int)hipGetLastError();
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+}
+template <class S> static ShapeFns make_shape_fns() {
+    ShapeFns f;
+    f.lds = make_fns<S, false>();
+    if constexpr (S::HAS_LOW) f.low = make_fns<S, true>();
+    if constexpr (LaneShape<S>::supported) f.fn_lane = (const void *)acme_lane_kernel<S>;
+    f.launch_lane = &launch_lane_shape<S>;
+    return f;
+}
+
+// The kernels are instantiated in ACME_NPARTS translation units (acme_hip_part<k>.hip: the shapes whose
+// number in ACME_SHAPES is k modulo ACME_NPARTS), compiled in parallel: the run kernel of one shape alone is
+// 10 ... 30 thousand instructions.  Each part answers for its own shapes.
+constexpr int ACME_NPARTS = 4;
+bool acme_shape_fns_part0(int index, ShapeFns *out);
+bool acme_shape_fns_part1(int index, ShapeFns *out);
+bool acme_shape_fns_part2(int index, ShapeFns *out);
+bool acme_shape_fns_part3(int index, ShapeFns *out);
 
 }  // namespace acme

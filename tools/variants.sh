@@ -10,7 +10,7 @@ if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
-        acme_jl_amd/csrc/acme_hip.hip acme_jl_amd/csrc/acme_hip_low.hip -o build_variants/libacme_hip_$name.so &
+        acme_jl_amd/csrc/acme_hip.hip acme_jl_amd/csrc/acme_hip_part[0-3].hip -o build_variants/libacme_hip_$name.so &
   done
   wait
 else
