@@ -117,6 +117,10 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %; the big one lost 1.5 % in round 2
     // and gains 1.6 % now that the run kernel's rare paths are laid out of line (round 3)
     static constexpr bool SOLVE_SPLIT = true;
+    // a launch's iteration total / maximum accumulated in registers by every lane instead of by LDS atomics
+    // under a one-lane EXEC: birdie +3.0 %, fixed-pot superover and headline +-0 (the big shape has no
+    // registers to spare and keeps the atomics)
+    static constexpr bool ITREG = !MULT;
     // constant lane predicates as literals of the scalar AND (and_rows): small shapes only
     static constexpr bool LITROWS = !MULT;
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
@@ -1315,6 +1319,8 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // kept in LDS (one copy per instance, updated by the instance's lane 0 once per sample)
     // rather than in registers of all 16 lanes: they are never needed inside the solver loop
     long long *rbuf = reinterpret_cast<long long *>(ybuf + S::YBUF);
+    double it_total = 0.0;     // Shape::ITREG: this launch's iteration total (exact in a double) and maximum, in registers
+    int it_max = 0;
     int dead = valid ? 0 : 1;  // dead: the reference would have thrown at first_nonfinite (an integer, like `stale`)
     if (valid) {
         const long long *rp = A.report + inst * RW_WORDS;
@@ -1518,7 +1524,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                         if (lig == 0 && die && rbuf[RW_FIRST_NONFINITE] < 0) rbuf[RW_FIRST_NONFINITE] = n;
                         dead = die ? 1 : dead;
                     }
-                    if (S::LITROWS ? and_rows<1ull, true>(alive) : (lig == 0 && alive)) {   // fire-and-forget LDS atomics: no round trip to wait for
+                    if constexpr (S::ITREG) {      // (every lane of the instance keeps the same two numbers: no EXEC games)
+                        const int itn = alive ? its_sample : 0;
+                        it_total += (double)itn;
+                        it_max = itn > it_max ? itn : it_max;
+                    } else if (S::LITROWS ? and_rows<1ull, true>(alive) : (lig == 0 && alive)) {   // fire-and-forget LDS atomics: no round trip to wait for
                         wv::lds_add(&rbuf[RW_ITERS_TOTAL], (long long)its_sample);
                         wv::lds_max(&rbuf[RW_ITERS_MAX], (long long)its_sample);
                     }
@@ -1680,6 +1690,13 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 for (int i = lig; i < S::CACHEPM; i += GROUP)
                     A.cache[inst * S::CACHEIH + s * S::CACHE1H + i] =
                         (i < NP * CACHE || !S::META_SCR) ? cache0[s * S::CACHE1 + i] : (i == NP * CACHE ? meta_scr[0] : 0.0);
+        if constexpr (S::ITREG) {
+            if (lig == 0 && !solve_mode) {
+                rbuf[RW_ITERS_TOTAL] += (long long)it_total;
+                rbuf[RW_ITERS_MAX] = rbuf[RW_ITERS_MAX] > it_max ? rbuf[RW_ITERS_MAX] : (long long)it_max;
+            }
+            wv::wave_fence();
+        }
         if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
     }
 }

@@ -2,6 +2,7 @@
 # Build kernel variants (extra -D flags) next to the product library and, on a GPU box, bench each.
 #   tools/variants.sh build  "name1:-DFLAG_A" "name2:-DFLAG_A -DFLAG_B" ...
 #   tools/variants.sh bench  [bench.py args]        (runs every build_variants/*.so)
+# A variant's translation units compile in parallel (the kernels are split over acme_hip_part<k>.hip).
 set -e
 cd "$(dirname "$0")/.."
 mode=$1; shift
@@ -9,10 +10,14 @@ if [ "$mode" = build ]; then
   mkdir -p build_variants
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
-        acme_jl_amd/csrc/acme_hip.hip acme_jl_amd/csrc/acme_hip_part[0-3].hip -o build_variants/libacme_hip_$name.so &
+    tmp=$(mktemp -d)
+    for tu in acme_hip acme_hip_part0 acme_hip_part1 acme_hip_part2 acme_hip_part3; do
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c acme_jl_amd/csrc/$tu.hip -o $tmp/$tu.o &
+    done
+    wait
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $tmp/*.o -o build_variants/libacme_hip_$name.so
+    rm -rf $tmp
   done
-  wait
 else
   for so in build_variants/*.so; do
     echo "== $so"
