@@ -21,6 +21,10 @@ def test_superover_grid_layout():
 def test_traffic_lookup_and_byte_model():
     assert bench.pmc_traffic("superover_grid", 8192, 44100) > 1.4e10     # committed PMC pass
     assert bench.pmc_traffic("superover_grid", 8192, 123) is None
+    # the steady-state counters the bench line's roofline object quotes (tools/profile_gpu.sh, tools/merge_pmc.py)
+    assert 0.0 < bench.pmc_lds_bank_conflict_frac("superover_grid", 8192, 44100) < 0.02
+    assert 0.6 < bench.pmc_valu_issue_frac("superover_grid", 8192, 44100) < 1.0
+    assert bench.pmc_lds_bank_conflict_frac("superover_grid", 8192, 123) is None
     from helpers import load
     m = load("superover_var")
     assert bench.algorithmic_bytes(m, 8192, 44100) == 8192 * 44100 * 40 + 8192 * 2 * 8 * (11 + 11 + 13)
