@@ -121,6 +121,10 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // under a one-lane EXEC: birdie +3.0 %, fixed-pot superover and headline +-0 (the big shape has no
     // registers to spare and keeps the atomics)
     static constexpr bool ITREG = !MULT;
+    // every fused broadcast chain waits its two states, not only the first to read a source: on the shapes
+    // whose registers the compiler spills to AGPRs a reload (v_accvgpr_read, a VALU write) can land right in
+    // front of any of them (tools/dpp_hazard_check.py found one)
+    static constexpr bool CHAINWAIT = NN > 13;
     // constant lane predicates as literals of the scalar AND (and_rows): small shapes only
     static constexpr bool LITROWS = !MULT;
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
@@ -398,8 +402,11 @@ template <int NN> struct RowLU {
         }
         // a zero pivot without a larger candidate (exactly singular A) or a NaN in A or b turns every row into
         // NaN; an infinite pivot leaves 1/pivot = 0 behind
-        if constexpr (GJHEAD) viol = wv::ballot(frz > PIVOT_THRESHOLD || !(b * 0.0 == 0.0) || dinv == 0.0);
-        else viol |= wv::ballot(!(b * 0.0 == 0.0) || dinv == 0.0);
+        // (one ballot per compare, OR-ed as scalar masks: the ballot of an OR of three booleans comes out as the
+        // three compares, a v_cndmask of the OR-ed mask and a fourth compare on that)
+        const unsigned long long bad = wv::ballot(!(b * 0.0 == 0.0)) | wv::ballot(dinv == 0.0);
+        if constexpr (GJHEAD) viol = wv::ballot(frz > PIVOT_THRESHOLD) | bad;
+        else viol |= bad;
         return viol;
     }
 
@@ -415,10 +422,7 @@ template <int NN> struct RowLU {
             mul[k] = v.lo;
             mul[k + 1] = v.hi;
         });
-        sfor<0, NN>([&](auto kc) ACME_LAMBDA {
-            constexpr int k = decltype(kc)::value;
-            wv::fmac_bcast_self<k, true>(b, mul[k]);
-        });
+        wv::fmac_self_chain<NN>(b, mul);
         b *= mul[NN];
     }
 
@@ -855,7 +859,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             }
             if constexpr (q0_in_pad) acc = pe[NP];
             if constexpr (S::FUSE) {       // one statement per term; the first one waits for p (DPP hazard)
-                wv::fmac_bcast_chain<NP, t == 0>(acc, p, pe);
+                wv::fmac_bcast_chain<NP, t == 0 || S::CHAINWAIT>(acc, p, pe);
             } else {
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
@@ -909,7 +913,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {      // one statement per term; the first one waits for zz
                 constexpr int t = decltype(tc_)::value;
-                wv::fmac_bcast_chain<NN, t == 0>(e[t], zz, fqv[t]);
+                wv::fmac_bcast_chain<NN, t == 0 || S::CHAINWAIT>(e[t], zz, fqv[t]);
             });
         }
         ACME_T2(TB_E1);
@@ -1019,7 +1023,8 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // instance changed its row order without storing a new origin, or a recorded elimination was
     // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
     int stale = 1;       // (an integer in a vector register, like the loop flags of base_solve)
-    auto linearize = [&](double zz, bool act, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
+    // (actm: the caller's ballot of `act` -- it has it anyway, as its loop condition)
+    auto linearize = [&](double zz, bool act, unsigned long long actm, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
         int okf = 1;     // `ok`: carried as an integer in a vector register
         bool want, recording, mine;
         double jp[NPr];
@@ -1036,19 +1041,20 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             double none[1] = {0.0};
             dz = res;
             recording = wv::ballot(want) != 0ull;
-            if (recording) {
-                if constexpr (S::MULT) {
-                    viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN), dinv);
-                } else {       // the columns of Jp ride along: jp <- J^-1 Jp
-                    calc_jp(jp);
-                    viol = LU::template solve_inplace<NP, false, S, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false, dinv);
-                }
+            if constexpr (S::MULT) {
+                // ONE elimination for iterates that become the origin and for those that do not: the recording
+                // costs no arithmetic (the multipliers exist anyway), only the predicated stores at its end
+                viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN), dinv);
+                ACME_T(TB_GJP);
+            } else if (recording) {       // the columns of Jp ride along: jp <- J^-1 Jp
+                calc_jp(jp);
+                viol = LU::template solve_inplace<NP, false, S, S::GJHEAD, S::SAFE0>(a, dz, jp, ojp, false, dinv);
                 ACME_T(TB_GJP);
             } else {
                 viol = LU::template solve_inplace<0, false, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, false, dinv);
                 ACME_T(TB_GJ0);
             }
-            viol &= wv::ballot(act || force);   // the other instances' results are not used
+            viol &= actm | wv::ballot(force);   // the other instances' results are not used
             mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
             return viol;
         };
@@ -1167,12 +1173,13 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         int fl = wv::keepi(need ? 1 : 0);
         its = 0;
         ACME_T(TB_SETUP);
-        while (wv::ballot((fl & 1) != 0)) {
+        unsigned long long actm;
+        while ((actm = wv::ballot((fl & 1) != 0)) != 0ull) {
             const bool act = (fl & 1) != 0;
             its += fl & 1;
             bool finite, ok, small;
             double dz;
-            linearize(z, act, false, finite, ok, small, dz);
+            linearize(z, act, actm, false, finite, ok, small, dz);
             const bool want = act && finite && ok && small;
             const bool stop_bad = act && (!finite || !ok);
             const bool step = act && !stop_bad && !want;
@@ -1211,7 +1218,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             const double dl = (lig < NP) ? target - lp : 0.0;
             const double best = wv::allsum16(dl * dl);
             double d = 0.0;
-            if constexpr (!S::FUSE) {
+            if constexpr (!S::FUSE || S::CHAINWAIT) {
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
                     const double t = cp[j * CACHE + (lig & (CACHE - 1))] - wv::bcast16<j>(target);
@@ -1245,7 +1252,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             set_p(lp);
             bool f0, k0, s0;
             double d0;
-            linearize(reorig ? lz : z, false, reorig, f0, k0, s0, d0);
+            linearize(reorig ? lz : z, false, 0ull, reorig, f0, k0, s0, d0);
         }
         const bool c = base_solve(target, need, its);
         if (caching) {
@@ -1563,7 +1570,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 }
                 double acc = w[0];
                 if constexpr (S::FUSE) {
-                    wv::fmac_bcast_chain<NX, false, 1>(acc, x[0], w);
+                    wv::fmac_bcast_chain<NX, S::CHAINWAIT, 1>(acc, x[0], w);
                 } else {
                     sfor<0, NX>([&](auto jc) ACME_LAMBDA {
                         constexpr int j = decltype(jc)::value;

@@ -114,6 +114,41 @@ template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(d
     }
 }
 #undef ACME_FB_CASE
+// The replay of a recorded elimination,  acc += (lane k of acc's row) * mul[k]  for k = 0 .. N-1,  as ONE
+// statement: every step reads through DPP what the step before wrote, so each carries its two wait states
+// (the hardware's, no interlock); as N statements the compiler added one more after each of them.
+#define ACME_FSS(j) "s_nop 1\n\tv_fmac_f64_dpp %[acc], %[acc], %[m" #j "] row_newbcast:%[k" #j "] row_mask:0xf bank_mask:0xf\n\t"
+#define ACME_FSS_1 ACME_FSS(0)
+#define ACME_FSS_2 ACME_FSS_1 ACME_FSS(1)
+#define ACME_FSS_3 ACME_FSS_2 ACME_FSS(2)
+#define ACME_FSS_4 ACME_FSS_3 ACME_FSS(3)
+#define ACME_FSS_5 ACME_FSS_4 ACME_FSS(4)
+#define ACME_FSS_6 ACME_FSS_5 ACME_FSS(5)
+#define ACME_FSS_7 ACME_FSS_6 ACME_FSS(6)
+#define ACME_FSS_8 ACME_FSS_7 ACME_FSS(7)
+#define ACME_FSS_9 ACME_FSS_8 ACME_FSS(8)
+#define ACME_FSS_10 ACME_FSS_9 ACME_FSS(9)
+#define ACME_FSS_11 ACME_FSS_10 ACME_FSS(10)
+#define ACME_FSS_12 ACME_FSS_11 ACME_FSS(11)
+#define ACME_FSS_13 ACME_FSS_12 ACME_FSS(12)
+#define ACME_FS_CASE(n) \
+    if constexpr (CNT == n) asm volatile(ACME_FSS_##n : [acc] "+v"(acc) : ACME_FBI_##n);
+template <int K0, int CNT, int M> ACME_DEV void fmac_self_seg(double &acc, const double (&mul)[M]) {
+    constexpr int OFF = 0;
+    static_assert(CNT >= 1 && CNT <= 13 && M >= K0 + CNT, "");
+    ACME_FS_CASE(1) ACME_FS_CASE(2) ACME_FS_CASE(3) ACME_FS_CASE(4) ACME_FS_CASE(5) ACME_FS_CASE(6) ACME_FS_CASE(7)
+    ACME_FS_CASE(8) ACME_FS_CASE(9) ACME_FS_CASE(10) ACME_FS_CASE(11) ACME_FS_CASE(12) ACME_FS_CASE(13)
+}
+template <int N, int M> ACME_DEV void fmac_self_chain(double &acc, const double (&mul)[M]) {
+    static_assert(N >= 1 && N <= 16, "one DPP row");
+    if constexpr (N <= 13) {
+        fmac_self_seg<0, N>(acc, mul);
+    } else {
+        fmac_self_seg<0, 13>(acc, mul);
+        fmac_self_seg<13, N - 13>(acc, mul);
+    }
+}
+#undef ACME_FS_CASE
 
 // two wait states before a run of fmac_bcast statements whose source may have just been produced
 ACME_DEV void dpp_wait() { asm volatile("s_nop 1"); }

@@ -173,6 +173,10 @@ template <int K> ACME_DEV int bcast16(int v) {
     return (int)(int64_t)emu::exchange((uint64_t)(int64_t)v, (lane & ~15) + K, 200 + K);
 }
 template <int K, bool SAFE> ACME_DEV void fmac_bcast_self(double &acc, double mul) { acc = fma(bcast16<K>(acc), mul, acc); }
+template <int I, int N, int M> ACME_DEV void fmac_self_chain_(double &acc, const double (&mul)[M]) {
+    if constexpr (I < N) { fmac_bcast_self<I, true>(acc, mul[I]); fmac_self_chain_<I + 1, N, M>(acc, mul); }
+}
+template <int N, int M> ACME_DEV void fmac_self_chain(double &acc, const double (&mul)[M]) { fmac_self_chain_<0, N, M>(acc, mul); }
 template <int K, bool SAFE> ACME_DEV double bcast16_ordered(double v) { return bcast16<K>(v); }
 template <int K> ACME_DEV void fmac_bcast(double &acc, double src, double mul) { acc = fma(bcast16<K>(src), mul, acc); }
 template <int I, int N, int OFF, int M> ACME_DEV void fmac_bcast_chain_(double &acc, double src, const double (&mul)[M]) {
