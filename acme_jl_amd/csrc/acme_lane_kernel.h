@@ -29,7 +29,6 @@
 namespace acme {
 
 constexpr int LANE_BLOCK = WAVES_PER_BLOCK * 64;   // instances per block (its waves never talk to each other)
-constexpr int LANE_TILE = 8;   // samples per u / y register tile (64 B per lane and input)
 
 template <class S> struct LaneShape {
     // LDS doubles per block: the stored p's of its instances' solution caches, cp[j][entry][lane]
@@ -187,6 +186,20 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     // work
     double pf[NN][NT], tv[NN][NT], res[NN], jm[NN][NN];
     int ipiv[NN];
+    // The lanes of `doit` take a new origin (factors f, pivots pv, Jp, p, z).  (The origin stays in registers:
+    // kept in LDS -- it is read once and written once per sample, but carried through every loop of the solver at
+    // a register copy per trip -- the LDS latency, which a lone wave has nothing to hide behind, cost 6 %.)
+    auto origin_store = [&](bool doit, const double (&f)[NN][NN], const int (&pv)[NN], const double (&jp)[NN][NPr],
+                            const double (&pp)[NPr], const double (&zz)[NN]) ACME_LAMBDA {
+        sfor<0, NN>([&](auto ic) ACME_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            oipiv[i] = doit ? pv[i] : oipiv[i];
+            sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[i][decltype(jc)::value] = sel(doit, f[i][decltype(jc)::value], olu[i][decltype(jc)::value]); });
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[i][decltype(jc)::value] = sel(doit, jp[i][decltype(jc)::value], ojp[i][decltype(jc)::value]); });
+            lz[i] = sel(doit, zz[i], lz[i]);
+        });
+        sfor<0, NP>([&](auto jc) ACME_LAMBDA { lp[decltype(jc)::value] = sel(doit, pp[decltype(jc)::value], lp[decltype(jc)::value]); });
+    };
 
     // pfull <- q0 + pexp p, only the (<= NT) entries every residual row needs (set_p, src/ACME.jl:237-243)
     auto set_p = [&](const double (&p)[NPr]) ACME_LAMBDA {
@@ -274,12 +287,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
         double jp[NN][NPr];
         calc_jp(jp);
         (void)lane_lu_factor<NN>(jm, ipiv);
-        sfor<0, NN>([&](auto ic) ACME_LAMBDA {
-            constexpr int i = decltype(ic)::value;
-            oipiv[i] = doit ? ipiv[i] : oipiv[i];
-            sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[i][decltype(jc)::value] = sel(doit, jm[i][decltype(jc)::value], olu[i][decltype(jc)::value]); });
-            sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[i][decltype(jc)::value] = sel(doit, jp[i][decltype(jc)::value], ojp[i][decltype(jc)::value]); });
-        });
+        origin_store(doit, jm, ipiv, jp, lp, lz);       // (lp, lz: the caller's, already those of the new origin)
     };
     // the factors and Jp at the origin are recomputed from the persistent (lp, lz) at launch start
     sfor<0, NN>([&](auto ic) ACME_LAMBDA {
@@ -307,7 +315,11 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
         sfor<0, NN>([&](auto ic) ACME_LAMBDA { z[decltype(ic)::value] = sel(need, lz[decltype(ic)::value] - t[decltype(ic)::value], z[decltype(ic)::value]); });
         bool act = need, conv = false, accepted = false;
         its = 0;
-        while (wv::ballot(act)) {
+        // (do-while: every update below is predicated on `act`, so a pass for a wave none of whose lanes needs
+        // one -- it does not happen on the direct attempt -- changes nothing; but what the loop hands on, the
+        // factors and Jq of the last pass, then needs no merge with the values from before a loop that might
+        // not run: a register copy each per iteration, 10 ... 40 of them)
+        do {
             its += act ? 1 : 0;
             const bool finite = evaluate(z);
             // resmaxabs < tol (src/solvers.jl:203,218): false for a NaN / inf residual, and independent of
@@ -326,7 +338,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             lane_lu_solve<NN>(jm, ipiv, dz);
             sfor<0, NN>([&](auto ic) ACME_LAMBDA { z[decltype(ic)::value] = sel(step, z[decltype(ic)::value] - dz[decltype(ic)::value], z[decltype(ic)::value]); });
             act = step && (its < A.maxiter);
-        }
+        } while (wv::ballot(act));
         // The accepted iterate is the new extrapolation origin (src/solvers.jl:227-233).  Taken HERE, once:
         // a lane that has stopped keeps its z, so every later pass of the loop (run for the lanes still
         // iterating) recomputes the same evaluate! and the same factors for it -- at the exit jm / ipiv / tv
@@ -334,14 +346,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
         if (wv::ballot(accepted)) {
             double jp[NN][NPr];
             calc_jp(jp);
-            sfor<0, NN>([&](auto ic) ACME_LAMBDA {
-                constexpr int i = decltype(ic)::value;
-                oipiv[i] = accepted ? ipiv[i] : oipiv[i];
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { olu[i][decltype(jc)::value] = sel(accepted, jm[i][decltype(jc)::value], olu[i][decltype(jc)::value]); });
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { ojp[i][decltype(jc)::value] = sel(accepted, jp[i][decltype(jc)::value], ojp[i][decltype(jc)::value]); });
-                lz[i] = sel(accepted, z[i], lz[i]);
-            });
-            sfor<0, NP>([&](auto jc) ACME_LAMBDA { lp[decltype(jc)::value] = sel(accepted, target[decltype(jc)::value], lp[decltype(jc)::value]); });
+            origin_store(accepted, jm, ipiv, jp, target, z);
         }
         return conv || accepted;
     };
@@ -355,29 +360,34 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 const double d = target[j] - lp[j];
                 best = fma(d, d, best);
             });
-            int idx = -1;
-            double cpv[CACHE][NPr];                     // all the stored p's first: ONE wait for the LDS
+            // nearest stored p: all the distances, their minimum as a tree (4 levels instead of a 16-deep chain of
+            // compare + three selects), and the ENTRY only when there is a hit -- the first one at the minimum,
+            // as the reference's scan in storing order finds it.  A NaN distance never wins (minNum).
+            double dist[CACHE];
             sfor<0, CACHE>([&](auto ec) ACME_LAMBDA {
-                constexpr int e = decltype(ec)::value;
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA {
-                    if constexpr (CREG) cpv[e][decltype(jc)::value] = cpr[decltype(jc)::value][e];
-                    else cpv[e][decltype(jc)::value] = cpl[(decltype(jc)::value * CACHE + e) * LANE_BLOCK];
-                });
-            });
-            sfor<0, CACHE>([&](auto ec) ACME_LAMBDA {    // nearest stored p, first one on ties
                 constexpr int e = decltype(ec)::value;
                 double d = 0.0;
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    const double tt = cpv[e][j] - target[j];
+                    double cv;
+                    if constexpr (CREG) cv = cpr[j][e];       // (slots never written hold +inf)
+                    else cv = cpl[(j * CACHE + e) * LANE_BLOCK];
+                    const double tt = cv - target[j];
                     d = fma(tt, tt, d);
                 });
-                const bool c = CREG ? d < best : (bool)((int)(e < ccount) & (int)(d < best));    // (&&: a branch per entry)
-                best = c ? d : best;
-                idx = c ? e : idx;
+                dist[e] = (CREG || e < ccount) ? d : (double)INFINITY;
             });
-            const bool hit = need && idx >= 0;
+            double mt[CACHE];
+            sfor<0, CACHE>([&](auto ec) ACME_LAMBDA { mt[decltype(ec)::value] = dist[decltype(ec)::value]; });
+            sfor<0, 4>([&](auto lc) ACME_LAMBDA {
+                constexpr int w = CACHE >> (decltype(lc)::value + 1);
+                sfor<0, w>([&](auto ec) ACME_LAMBDA { mt[decltype(ec)::value] = __builtin_fmin(mt[decltype(ec)::value], mt[decltype(ec)::value + w]); });
+            });
+            static_assert(CACHE == 16, "four levels");
+            const bool hit = need && mt[0] < best;
             if (ACME_RARE(wv::ballot(hit))) {
+                int idx = 0;
+                sfor_down<CACHE>([&](auto ec) ACME_LAMBDA { idx = dist[decltype(ec)::value] == mt[0] ? decltype(ec)::value : idx; });
                 const int e = hit ? idx : 0;
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
@@ -386,7 +396,6 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                     else v = cpl[(j * CACHE + e) * LANE_BLOCK];
                     lp[j] = hit ? v : lp[j];
                 });
-                (void)cpv;
                 sfor<0, NN>([&](auto ic) ACME_LAMBDA {
                     constexpr int i = decltype(ic)::value;
                     const double v = cag[S::CACHE1 + e * NN + i];
@@ -420,36 +429,35 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     const int nu_io = A.nu_io, ny_io = A.ny_io;
     const double *ug = A.u + ii * T * nu_io;
     double *yg = A.y + ii * T * ny_io;
-    // u / y tiles live in registers.  Register arrays cannot be indexed by the (runtime) sample
-    // number, so they work as shift registers: every sample takes the front entries of ucur and
-    // appends its outputs to the back of ybuf (a handful of moves per sample, and ONE copy of the
-    // sample body in the code instead of LANE_TILE).
-    double ucur[LANE_TILE * NUr], unext[LANE_TILE * NUr], ybuf[LANE_TILE * NYr];
-    // (one predicate for the whole tile: samples past the end re-read the last one, inputs the model
-    // does not have re-read input 0 -- a branch per entry costs more than the loads)
-    auto fetch = [&](long long n0, double (&dst)[LANE_TILE * NUr]) ACME_LAMBDA {
-        sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA { dst[decltype(ec)::value] = 0.0; });
-        if (valid && n0 < T && nu_io > 0) {      // (a model without inputs has u == NULL: run!(model, zeros(0, T)))
-            sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA {
-                constexpr int e = decltype(ec)::value;
-                const long long n = n0 + e / NUr;
-                const int k = e % NUr;
-                dst[e] = ug[(n < T ? n : T - 1) * nu_io + (k < nu_io ? k : 0)];
+    // u and y go straight to and from HBM, one sample at a time: the inputs of sample n + 1 are requested
+    // before sample n is worked on (a sample takes a lone wave ~2.5 us, several memory latencies), y is
+    // stored as it is formed.  A lane touches 8 bytes of its own row per access -- a 64-byte line serves 8
+    // consecutive samples out of the L2, so HBM sees every byte once.  (Rounds 1-2 kept 8-sample tiles in
+    // registers as shift registers: 8 ... 30 register moves per sample, half of them through AGPRs.)
+    auto fetch = [&](long long n, double (&dst)[NUr]) ACME_LAMBDA {
+        // (no per-lane predicate: an idle lane reads instance 0's row; a model without inputs has u == NULL --
+        // run!(model, zeros(0, T)) -- and takes the uniform branch)
+        if (nu_io > 0) {
+            sfor<0, NU>([&](auto kc) ACME_LAMBDA {
+                constexpr int k = decltype(kc)::value;
+                dst[k] = ug[(n < T ? n : T - 1) * nu_io + (k < nu_io ? k : 0)];   // past the end: the last sample again
             });
+        } else {
+            sfor<0, NU>([&](auto kc) ACME_LAMBDA { dst[decltype(kc)::value] = 0.0; });
         }
     };
-    sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA { ybuf[decltype(ec)::value] = 0.0; });
+    double unext[NUr];
     fetch(0, unext);
-    for (long long n0 = 0; n0 < T; n0 += LANE_TILE) {
-        sfor<0, LANE_TILE * NU>([&](auto ec) ACME_LAMBDA { ucur[decltype(ec)::value] = unext[decltype(ec)::value]; });
-        fetch(n0 + LANE_TILE, unext);                   // the next tile arrives while this one is worked on
-        const int cnt = (int)((T - n0 < LANE_TILE) ? (T - n0) : LANE_TILE);
-        for (int m = 0; m < cnt; ++m) {
-            const long long n = A.sample_base + n0 + m;
+    // (waited for before the loop: a value entering the loop in flight makes the compiler wait at its first
+    // use in EVERY iteration -- right behind the load of the next one)
+    sfor<0, NU>([&](auto kc) ACME_LAMBDA { unext[decltype(kc)::value] = wv::keep(unext[decltype(kc)::value]); });
+    {
+        for (long long n1 = 0; n1 < T; ++n1) {
+            const long long n = A.sample_base + n1;
             const bool alive = !dead;
             double us[NUr];
-            sfor<0, NU>([&](auto kc) ACME_LAMBDA { us[decltype(kc)::value] = ucur[decltype(kc)::value]; });
-            sfor<0, (LANE_TILE - 1) * NU>([&](auto ec) ACME_LAMBDA { ucur[decltype(ec)::value] = ucur[decltype(ec)::value + NU]; });
+            sfor<0, NU>([&](auto kc) ACME_LAMBDA { us[decltype(kc)::value] = unext[decltype(kc)::value]; });
+            fetch(n1 + 1, unext);
             // p = dq x + eq u  (src/ACME.jl:678-686)
             double p[NPr];
             sfor<0, NP>([&](auto ic) ACME_LAMBDA {
@@ -522,8 +530,11 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             r_iters_total += alive ? its_sample : 0;
             r_iters_max = (alive && its_sample > r_iters_max) ? its_sample : r_iters_max;
             const bool live = !dead;
+            // the next sample's inputs have arrived by now: a use HERE, so that the wait sits at the end of the
+            // sample and not -- for a value still in flight across the loop's back edge -- right behind the load;
+            // and before y is stored, or it would wait for that store as well
+            sfor<0, NU>([&](auto kc) ACME_LAMBDA { unext[decltype(kc)::value] = wv::keep(unext[decltype(kc)::value]); });
             // y = y0 + dy x + ey u + fy z with the OLD x (:699-706), then x = x0 + a x + b u + c z (:708-714)
-            sfor<0, (LANE_TILE - 1) * NY>([&](auto ec) ACME_LAMBDA { ybuf[decltype(ec)::value] = ybuf[decltype(ec)::value + NY]; });
             sfor<0, NY>([&](auto ic) ACME_LAMBDA {
                 constexpr int i = decltype(ic)::value;
                 const auto R = row_ptr(LL.y0 + i * LL.xstr);
@@ -531,7 +542,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 sfor<0, NX>([&](auto jc) ACME_LAMBDA { acc = fma(R[1 + decltype(jc)::value], x[decltype(jc)::value], acc); });
                 sfor<0, NU>([&](auto kc) ACME_LAMBDA { acc = fma(R[1 + NX + decltype(kc)::value], us[decltype(kc)::value], acc); });
                 sfor<0, NN>([&](auto jc) ACME_LAMBDA { acc = fma(R[1 + NX + NU + decltype(jc)::value], alive ? z[decltype(jc)::value] : 0.0, acc); });
-                ybuf[(LANE_TILE - 1) * NY + i] = live ? acc : (double)NAN;
+                if (valid && i < ny_io) yg[n1 * ny_io + i] = live ? acc : (double)NAN;
             });
             double xn[NXr];
             sfor<0, NX>([&](auto ic) ACME_LAMBDA {
@@ -544,17 +555,6 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 xn[i] = acc;
             });
             sfor<0, NX>([&](auto ic) ACME_LAMBDA { x[decltype(ic)::value] = sel(live, xn[decltype(ic)::value], x[decltype(ic)::value]); });
-        }
-        // flush: the cnt outputs of this tile sit at the BACK of ybuf
-        if (cnt == LANE_TILE && ny_io == NY) {                // the usual tile: one predicate for all of it
-            if (valid) sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA { yg[n0 * NY + decltype(ec)::value] = ybuf[decltype(ec)::value]; });
-        } else {
-            sfor<0, LANE_TILE * NY>([&](auto ec) ACME_LAMBDA {
-                constexpr int e = decltype(ec)::value;
-                const int ms = e / NYr - (LANE_TILE - cnt);     // sample within the tile
-                const int k = e % NYr;
-                if (valid && ms >= 0 && k < ny_io) yg[(n0 + ms) * ny_io + k] = ybuf[e];
-            });
         }
     }
 

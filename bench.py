@@ -417,6 +417,8 @@ def main():
     ms_total, launches = runner.kernel_time()
     last_ms = ms_total / max(launches, 1)
     ra = runner.report_arrays()
+    if os.environ.get("ACME_BENCH_DUMP_ITERS"):      # per-instance iteration totals of the timed steps (tools/blockload.py)
+        np.save(os.environ["ACME_BENCH_DUMP_ITERS"], np.asarray(ra["iters_total"].cpu() if hasattr(ra["iters_total"], "cpu") else ra["iters_total"]))
     stats = torch.tensor([elapsed, float(ra["iters_total"].sum()), float(ra["n_warn"].sum()),
                           float((ra["first_nonfinite"] >= 0).sum()), float(ra["iters_max"].max()),
                           last_ms], dtype=torch.float64, device=dev)
