@@ -121,10 +121,11 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // under a one-lane EXEC: birdie +3.0 %, fixed-pot superover and headline +-0 (the big shape has no
     // registers to spare and keeps the atomics)
     static constexpr bool ITREG = !MULT;
-    // every fused broadcast chain waits its two states, not only the first to read a source: on the shapes
-    // whose registers the compiler spills to AGPRs a reload (v_accvgpr_read, a VALU write) can land right in
+    // every fused broadcast chain waits its two states, not only the first to read a source (and the cache
+    // lookup's single fused operations are not used at all): on the shapes whose registers the compiler spills
+    // to AGPRs -- the generic ones, with every element kind's code -- a reload (v_accvgpr_read, a VALU write) can land right in
     // front of any of them (tools/dpp_hazard_check.py found one)
-    static constexpr bool CHAINWAIT = NN > 13;
+    static constexpr bool CHAINWAIT = RARE || NN > 13;
     static constexpr bool ACTM = NN >= 7;
     // constant lane predicates as literals of the scalar AND (and_rows): small shapes only
     static constexpr bool LITROWS = !MULT;
@@ -1178,8 +1179,8 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         int fl = wv::keepi(need ? 1 : 0);
         its = 0;
         ACME_T(TB_SETUP);
-        unsigned long long actm;
-        while ((actm = wv::ballot((fl & 1) != 0)) != 0ull) {
+        unsigned long long actm = wv::ballot((fl & 1) != 0);
+        do {
             const bool act = (fl & 1) != 0;
             its += fl & 1;
             bool finite, ok, small;
@@ -1197,7 +1198,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             nf = (step && its < maxiter_v) ? (nf | 1) : nf;
             fl = wv::keepi(nf);
             ACME_T(TB_GLUE);
-        }
+        } while ((actm = wv::ballot((fl & 1) != 0)) != 0ull);
         const bool accepted = (fl & 4) != 0;
         lz = sel(accepted, z, lz);
         lp = sel(accepted, target, lp);
