@@ -175,41 +175,10 @@ ACME_DEV unsigned long long mask_shl1(unsigned long long m) {
 //   dinv = inv         (in the lanes of pivlanes)     (the pivot row remembers 1/pivot)
 //   pivlanes <<= 1 for the next step.  (The |nlm| > 4 ballot stays outside: as an output of a
 //   statement that also has vector outputs the compiler would treat the mask as divergent.)
-// SAFE: ak may have been written within the two preceding wait states.  Inside: one wait state
-// between the transcendental v_rcp_f64 and its first use; EXEC is only written by SALU
+// SAFE: ak may have been written within the two preceding wait states.  Inside: the wait state between the
+// transcendental v_rcp_f64 and its first use is the step's own mask shift (into a second scalar pair: the
+// unshifted mask is still needed for the narrowed EXEC) instead of an s_nop; EXEC is only written by SALU
 // instructions, which neither DPP nor VALU instructions have to wait for.
-template <int K, bool SAFE>
-ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz) {
-    double piv, inv, e;
-    unsigned long long sv;
-#define ACME_GJ_HEAD_BODY                                                                          \
-        "v_mov_b64_dpp %[piv], %[ak] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"          \
-        "v_rcp_f64_e32 %[inv], %[piv]\n\t"                                                       \
-        "s_nop 0\n\t"                                                                            \
-        "v_fma_f64 %[e], -%[piv], %[inv], 1.0\n\t"                                               \
-        "v_fmac_f64_e32 %[e], %[e], %[e]\n\t"                                                    \
-        "v_fmac_f64_e32 %[inv], %[inv], %[e]\n\t"                                                \
-        "v_mul_f64 %[nlm], %[ak], -%[inv]\n\t"                                                   \
-        "s_and_saveexec_b64 %[sv], %[m]\n\t"                                                     \
-        "v_mov_b64 %[dinv], %[inv]\n\t"                                                          \
-        "v_mov_b64 %[nlm], 0\n\t"                                                                \
-        "v_mov_b64 %[frz], %[vmx]\n\t"                                                           \
-        "s_mov_b64 exec, %[sv]\n\t"                                                              \
-        "s_lshl_b64 %[m], %[m], 1\n\t"                                                           \
-        "v_max_f64 %[vmx], %[vmx], |%[nlm]|"
-    if (SAFE)
-        asm volatile("s_nop 1\n\t" ACME_GJ_HEAD_BODY
-                     : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),
-                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz)
-                     : [ak] "v"(ak), [k] "n"(K) : "scc");
-    else
-        asm volatile(ACME_GJ_HEAD_BODY
-                     : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),
-                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz)
-                     : [ak] "v"(ak), [k] "n"(K) : "scc");
-#undef ACME_GJ_HEAD_BODY
-}
-
 // One WHOLE Gauss-Jordan step as (at most two) asm statements: the step head above followed by the row updates
 //   r[j] += (lane K of r[j]'s row) * nlm      for the CNT registers r[] (the columns right of the pivot, b)
 // Between separate statements the compiler assumes a dst-forwarding hazard and inserts a wait state: two per
@@ -240,7 +209,7 @@ ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes
 #define ACME_GJ_HEAD_TEXT                                                                          \
         "v_mov_b64_dpp %[piv], %[ak] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"          \
         "v_rcp_f64_e32 %[inv], %[piv]\n\t"                                                       \
-        "s_nop 0\n\t"                                                                            \
+        "s_lshl_b64 %[mn], %[m], 1\n\t"                                                          \
         "v_fma_f64 %[e], -%[piv], %[inv], 1.0\n\t"                                               \
         "v_fmac_f64_e32 %[e], %[e], %[e]\n\t"                                                    \
         "v_fmac_f64_e32 %[inv], %[inv], %[e]\n\t"                                                \
@@ -250,19 +219,18 @@ ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes
         "v_mov_b64 %[nlm], 0\n\t"                                                                \
         "v_mov_b64 %[frz], %[vmx]\n\t"                                                           \
         "s_mov_b64 exec, %[sv]\n\t"                                                              \
-        "s_lshl_b64 %[m], %[m], 1\n\t"                                                           \
         "v_max_f64 %[vmx], %[vmx], |%[nlm]|\n\t"
 #define ACME_GJ_A(n)                                                                                          \
     if constexpr (NA == n) {                                                                                  \
         constexpr int O = 0;                                                                                  \
         if (SAFE) asm volatile("s_nop 1\n\t" ACME_GJ_HEAD_TEXT ACME_FSELF_##n                                  \
                      : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),  \
-                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz), ACME_RSELF_##n    \
-                     : [ak] "v"(ak), [k] "n"(K) : "scc");                                                      \
+                       [sv] "=&s"(sv), [mn] "=&s"(mnext), [vmx] "+v"(vmx), [frz] "+v"(frz), ACME_RSELF_##n   \
+                     : [ak] "v"(ak), [m] "s"(pivlanes), [k] "n"(K) : "scc");                                                      \
         else asm volatile(ACME_GJ_HEAD_TEXT ACME_FSELF_##n                                                     \
                      : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [nlm] "=&v"(nlm), [dinv] "+v"(dinv),  \
-                       [sv] "=&s"(sv), [m] "+s"(pivlanes), [vmx] "+v"(vmx), [frz] "+v"(frz), ACME_RSELF_##n    \
-                     : [ak] "v"(ak), [k] "n"(K) : "scc");                                                      \
+                       [sv] "=&s"(sv), [mn] "=&s"(mnext), [vmx] "+v"(vmx), [frz] "+v"(frz), ACME_RSELF_##n   \
+                     : [ak] "v"(ak), [m] "s"(pivlanes), [k] "n"(K) : "scc");                                                      \
     }
 #define ACME_GJ_B(n)                                                                                          \
     if constexpr (CNT - NA == n) {                                                                            \
@@ -275,8 +243,9 @@ ACME_DEV void gj_step(double ak, double &dinv, unsigned long long &pivlanes, dou
     static_assert(CNT >= 1 && CNT <= 16, "");
     constexpr int NA = CNT < 7 ? CNT : 7;
     double piv, inv, e;
-    unsigned long long sv;
+    unsigned long long sv, mnext;
     ACME_GJ_A(1) ACME_GJ_A(2) ACME_GJ_A(3) ACME_GJ_A(4) ACME_GJ_A(5) ACME_GJ_A(6) ACME_GJ_A(7)
+    pivlanes = mnext;
     ACME_GJ_B(1) ACME_GJ_B(2) ACME_GJ_B(3) ACME_GJ_B(4) ACME_GJ_B(5) ACME_GJ_B(6) ACME_GJ_B(7) ACME_GJ_B(8) ACME_GJ_B(9)
 }
 #undef ACME_GJ_A
