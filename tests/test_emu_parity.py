@@ -529,3 +529,29 @@ def test_emulated_per_instance_matrices_beyond_lds(emu_lib):
     assert r.kernel_shape()[:3] == (8, 24, 8)
     yref, _ = oracle_run(mv, uv, cache_limit=16)
     assert_close(r.run(uv), yref)
+
+
+@pytest.mark.parametrize("name,lane", [("diodeclipper", "1"), ("diodeclipper", "0"), ("superover_fixed", "1")])
+def test_emulated_whole_wave_dead(emu_lib, name, lane, monkeypatch):
+    """Every instance of a wave hits a non-finite input at the same sample: from then on no lane of the wave needs a
+    solve, and the solver's do-while Newton loop runs its surplus pass with every update masked -- outputs are
+    NaN from that sample on, the iteration counters stop, and the samples before it are those of an undisturbed run."""
+    monkeypatch.setenv("ACME_LANE_KERNEL", lane)
+    m = load(name)
+    N, T, K = 3, 12, 5
+    u = sweep_inputs(name, N, T)
+    ref = emu_runner(emu_lib, m, N)
+    yref = ref.run(u[:, :, :K])
+    its_ref = ref.report_arrays()["iters_total"].copy()
+    ub = u.copy()
+    ub[:, 0, K] = np.inf
+    r = emu_runner(emu_lib, m, N)
+    y = r.run(ub, check=False)
+    ra = r.report_arrays()
+    assert ra["first_nonfinite"].tolist() == [K] * N
+    assert np.array_equal(y[:, :, :K], yref) and np.isnan(y[:, :, K:]).all()
+    # the fatal sample's own iterations are counted (the solve ran before step! noticed), nothing after it
+    r2 = emu_runner(emu_lib, m, N)
+    r2.run(ub[:, :, :K + 1], check=False)
+    assert np.array_equal(ra["iters_total"], r2.report_arrays()["iters_total"])
+    assert (ra["iters_total"] >= its_ref).all()

@@ -626,3 +626,26 @@ def test_nonlinear_model_without_inputs(hip_lib, lane_kernel, monkeypatch):
     yref, _ = oracle_run(m, u[:1])
     assert_close(y[:1], yref, rtol=RTOL_SAME)
     assert np.array_equal(y, np.tile(y[:1], (70, 1, 1))) and 0.6 < y[0, 0, -1] < 0.7
+
+
+@pytest.mark.parametrize("name,lane", [("diodeclipper", "1"), ("diodeclipper", "0"), ("superover_var", "1")])
+def test_whole_wave_dead(hip_lib, name, lane, monkeypatch):
+    """Every instance of a wave hits a non-finite input at the same sample: from then on no lane of the wave needs a
+    solve and the do-while Newton loop runs its surplus pass with every update masked.  Outputs are NaN from that
+    sample on, the iteration counters stop, the samples before it are bit for bit those of an undisturbed run."""
+    monkeypatch.setenv("ACME_LANE_KERNEL", lane)
+    m = load(name)
+    N, T, K = 4, 40, 17
+    u = sweep_inputs(name, N, T)
+    ref = runner(hip_lib, m, N)
+    yref = ref.run(u[:, :, :K])
+    ub = u.copy()
+    ub[:, 0, K] = np.inf
+    r = runner(hip_lib, m, N)
+    y = r.run(ub, check=False)
+    ra = r.report_arrays()
+    assert ra["first_nonfinite"].tolist() == [K] * N
+    assert np.array_equal(y[:, :, :K], yref) and np.isnan(y[:, :, K:]).all()
+    r2 = runner(hip_lib, m, N)
+    r2.run(ub[:, :, :K + 1], check=False)
+    assert np.array_equal(ra["iters_total"], r2.report_arrays()["iters_total"])
