@@ -439,12 +439,19 @@ template <int NN> struct RowLU {
         orig = lig;
         sfor<0, NN>([&](auto kc) ACME_LAMBDA {
             constexpr int k = decltype(kc)::value;
-            double v = lig_in<k, NN>() ? fabs(a[k]) : -1.0;
+            // (nn >= 7: the lane predicates are materialised on the spot, wv::lanes_here -- hoisted to the top of the
+            // kernel, the 3 x nn constants were 430 of the headline kernel's 483 spilled scalar registers; the
+            // birdie's nn = 4 kernel measures 1 % slower with it and keeps the hoisted form)
+            constexpr bool HERE = NN >= 7;
+            auto in_k = [&]() ACME_LAMBDA { if constexpr (HERE) return wv::lanes_here<((1u << NN) - 1u) & ~((1u << k) - 1u)>(); else return lig_in<k, NN>(); };
+            auto eq_k = [&]() ACME_LAMBDA { if constexpr (HERE) return wv::lanes_here<1u << k>(); else return lig_eq<k>(); };
+            auto gt_k = [&]() ACME_LAMBDA { if constexpr (HERE) return wv::lanes_here<(0xFFFFu << (k + 1)) & 0xFFFFu>(); else return lig_gt<k>(); };
+            double v = in_k() ? fabs(a[k]) : -1.0;
             double m = wv::allmax16(v);
             unsigned long long bal = wv::ballot(v == m);
             int msk = (int)((bal >> (grp * GROUP)) & 0xFFFFull);
             int kp = wv::ffs32(msk) - 1;          // first row holding the maximum
-            int src = lig_eq<k>() ? kp : ((lig == kp) ? k : lig);   // interchange rows k <-> kp
+            int src = eq_k() ? kp : ((lig == kp) ? k : lig);   // interchange rows k <-> kp
             sfor<k, NN>([&](auto jc) ACME_LAMBDA {  // columns < k are dead
                 constexpr int j = decltype(jc)::value;
                 a[j] = wv::shfl16(a[j], src);
@@ -452,7 +459,7 @@ template <int NN> struct RowLU {
             orig = wv::shfl16(orig, src);
             double piv = wv::bcast16<k>(a[k]);
             ok = ok && (piv != 0.0);
-            double lm = lig_gt<k>() ? a[k] * wv::recip(piv) : 0.0;   // l_ik, 0 on rows <= k
+            double lm = gt_k() ? a[k] * wv::recip(piv) : 0.0;   // l_ik, 0 on rows <= k
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
                 a[j] = fma(-lm, wv::bcast16<k>(a[j]), a[j]);

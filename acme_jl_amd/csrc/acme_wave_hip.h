@@ -313,6 +313,15 @@ ACME_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(
 // per-lane predicate from a wave-uniform 64-bit lane mask (compile-time constants become two
 // s_mov_b32 feeding v_cndmask directly: no v_cmp, no long-lived SGPR pair)
 ACME_DEV bool lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// ... of a constant pattern (the same 16 bits in every row), materialised HERE: for cold code.  Left to itself the
+// compiler hoists such constants -- 39 of them for the 13 steps of pivot_order -- to the top of the kernel, cannot
+// keep them in scalar registers across the hot loops and spills every one (2 v_writelane at launch, 2 v_readlane per
+// use): most of the kernel's "spilled SGPRs".  A volatile statement is neither hoisted nor merged.
+template <unsigned ROW16> ACME_DEV bool lanes_here() {
+    unsigned half;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(half) : "n"((ROW16 & 0xFFFFu) * 0x10001u));
+    return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)half << 32) | half);
+}
 
 // 1/x: v_rcp_f64 seed (relative error 2^-24.4, measured: tools/ubench/rcpacc.hip) refined by one
 // cubically convergent step  x (1 + e + e^2),  e = 1 - d x  (truncation e^3 = 2^-73): 3 fused

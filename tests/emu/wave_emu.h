@@ -267,4 +267,5 @@ ACME_DEV void sched_fence() {}
 ACME_DEV void lds_add(long long *p, long long v) { *p += v; }
 ACME_DEV void lds_max(long long *p, long long v) { if (v > *p) *p = v; }
 ACME_DEV bool lanes(unsigned long long mask) { return (mask >> (tid() & 63)) & 1ull; }
+template <unsigned ROW16> ACME_DEV bool lanes_here() { return lanes((unsigned long long)(ROW16 & 0xFFFFu) * 0x0001000100010001ull); }
 }  // namespace wv
