@@ -475,7 +475,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
             sfor<0, NP>([&](auto jc) ACME_LAMBDA { target[decltype(jc)::value] = p[decltype(jc)::value]; startp[decltype(jc)::value] = 0.0; });
             // The direct attempt first, outside any loop: it almost always settles the sample, and as
             // straight-line code it costs none of the register copies a loop head needs for everything that
-            // lives across it (the solution cache, the u / y tiles, the origin: ~120 moves per sample as a
+            // lives across it (the solution cache, the origin, the state: ~120 moves per sample as a
             // loop).  The bisection loop -- a second, cold copy of the solver -- only runs when an instance's
             // direct attempt failed.
             auto hstep = [&](bool c) ACME_LAMBDA {          // bookkeeping of solve(::HomotopySolver) after one base solve
