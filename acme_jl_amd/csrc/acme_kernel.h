@@ -127,6 +127,7 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // front of any of them (tools/dpp_hazard_check.py found one)
     static constexpr bool CHAINWAIT = RARE || NN > 13;
     static constexpr bool ACTM = NN >= 7;
+    static constexpr bool EXP2 = NN >= 7 && !RARE;
     // constant lane predicates as literals of the scalar AND (and_rows): small shapes only
     static constexpr bool LITROWS = !MULT;
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
@@ -416,14 +417,16 @@ template <int NN> struct RowLU {
     // operations, in the same order, the right-hand side would have seen riding along as an
     // augmented column.  Every step reads, through DPP, the register the previous step wrote: the
     // SAFE forms supply the two wait states.
-    template <class SH> static ACME_DEV void apply_stored(double &b, const double *slab) {
-        double mul[NN + 2];                       // the row's multipliers and 1/pivot, two slots per LDS read
-        sfor<0, (NN + 2) / 2>([&](auto kc) ACME_LAMBDA {
+    // (in two halves, so that the caller can request the entry long before it has the right-hand side)
+    template <class SH> static ACME_DEV void load_stored(double (&mul)[NN + 2], const double *slab) {
+        sfor<0, (NN + 2) / 2>([&](auto kc) ACME_LAMBDA {       // the row's multipliers and 1/pivot, two slots per LDS read
             constexpr int k = 2 * decltype(kc)::value;
             const wv::pair_t v = wv::ld2(&slab[SH::oslot(k)]);
             mul[k] = v.lo;
             mul[k + 1] = v.hi;
         });
+    }
+    static ACME_DEV void apply_loaded(double &b, const double (&mul)[NN + 2]) {
         wv::fmac_self_chain<NN>(b, mul);
         b *= mul[NN];
     }
@@ -849,6 +852,28 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
             wv::sched_fence();
         }
+        if constexpr (S::FUSE && L.pairs) {
+            // batch first: all three terms' pexp rows are requested before the first chain runs (round 2's
+            // load - wait - chain per term exposed the LDS latency three times a sample; registers are not
+            // scarce here, before the solve)
+            double pe[NT][NPr + 1];
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * grow]);
+                    pe[t][j] = v.lo;
+                    pe[t][j + 1] = v.hi;
+                });
+            });
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                double acc = (NP % 2 == 1) ? pe[t][NP] : Ms[L.q0i(t, 0) + grow];   // (odd np: q0 rides in the pad column)
+                wv::fmac_bcast_chain<NP, t == 0 || S::CHAINWAIT>(acc, p, pe[t]);
+                pf[t] = acc;
+            });
+            return;
+        }
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
             // (pair layout with an odd np: the pad column of the last pair holds q0, see acme_pack.h)
@@ -943,7 +968,10 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 urc[2 * p + 1] = v.hi;
             });
             const double sA = urc[0], sB = urc[1];
-            if (ACME_USUAL(has_bjt)) {                                // sA/sB = 0: exp(0) = 1
+            // (EXP2: no branch at all -- a row without a second junction has sB = 0, and exp_junction2 returns
+            // exactly 1 for it, as the other path sets it; a model without any BJT in one of these shapes
+            // pays ~20 wasted instructions per row evaluation, every other one saves a taken branch)
+            if (S::EXP2 || ACME_USUAL(has_bjt)) {                     // sA/sB = 0: exp(0) = 1
                 exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
             } else {
                 // (big shape: this path -- models without a BJT -- keeps the scalar table; on the register
@@ -1153,6 +1181,8 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
     // returns hasconverged, leaves needediterations in `its`.
     auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
+        double mul[NN + 2];
+        if constexpr (S::MULT) LU::template load_stored<S>(mul, ojp);     // requested first: needed last, ~60 instructions on
         set_p(target);
         // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215).  Row r of
         // last_Jp (p - last_p) is  sum_t Jq[r, tc_t] (pfull(p) - pfull(last_p))[tc_t]  (Jp = Jq pexp,
@@ -1172,7 +1202,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 constexpr int tt = decltype(tc_)::value;
                 t = fma(otp[S::OS_TV - s0 + tt], pf[tt] - otp[S::OS_PF - s0 + tt], t);
             });
-            LU::template apply_stored<S>(t, ojp);
+            LU::apply_loaded(t, mul);
         } else {       // the slab holds J^-1 Jp, row lig
             const double dp = target - lp;
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
