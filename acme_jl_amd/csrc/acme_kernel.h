@@ -847,61 +847,44 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // lane's row needs
     // (FUSE: p_j reaches the lanes through the DPP operand of the multiply-add itself, see fmac_bcast)
     auto set_p = [&](double p) ACME_LAMBDA {
-        double pb[NPr];
-        if constexpr (!S::FUSE) {
-            sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
-            wv::sched_fence();
-        }
-        if constexpr (S::FUSE && L.pairs) {
-            // batch first: all three terms' pexp rows are requested before the first chain runs (round 2's
-            // load - wait - chain per term exposed the LDS latency three times a sample; registers are not
-            // scarce here, before the solve)
-            double pe[NT][NPr + 1];
-            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
-                constexpr int t = decltype(tc_)::value;
+        // Batch first: the pexp rows (and q0) of all three terms are requested before the first multiply-add runs.
+        // (Rounds 1-2 went load - wait - accumulate term by term behind a scheduling fence, to bound the registers
+        // in flight: that exposed the LDS latency three times a sample, and registers are not scarce here,
+        // before the solve.)
+        // (pair layout with an odd np: the pad column of the last pair holds q0, see acme_pack.h)
+        constexpr bool q0_in_pad = L.pairs && (NP % 2 == 1);
+        double pe[NT][NPr + 1], q0v[NT];
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+            constexpr int t = decltype(tc_)::value;
+            if constexpr (L.pairs) {
                 sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = 2 * decltype(jc)::value;
                     const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * grow]);
                     pe[t][j] = v.lo;
                     pe[t][j + 1] = v.hi;
                 });
-            });
-            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
-                constexpr int t = decltype(tc_)::value;
-                double acc = (NP % 2 == 1) ? pe[t][NP] : Ms[L.q0i(t, 0) + grow];   // (odd np: q0 rides in the pad column)
-                wv::fmac_bcast_chain<NP, t == 0 || S::CHAINWAIT>(acc, p, pe[t]);
-                pf[t] = acc;
-            });
-            return;
+            } else {
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[t][decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + grow]; });
+            }
+            if constexpr (!q0_in_pad) q0v[t] = Ms[L.q0i(t, 0) + grow];
+        });
+        double pb[NPr];
+        if constexpr (!S::FUSE) {
+            sfor<0, NP>([&](auto jc) ACME_LAMBDA { pb[decltype(jc)::value] = wv::bcast16<decltype(jc)::value>(p); });
+            wv::sched_fence();
         }
         sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
             constexpr int t = decltype(tc_)::value;
-            // (pair layout with an odd np: the pad column of the last pair holds q0, see acme_pack.h)
-            constexpr bool q0_in_pad = L.pairs && (NP % 2 == 1);
-            double acc = 0.0;
-            if constexpr (!q0_in_pad) acc = Ms[L.q0i(t, 0) + grow];
-            double pe[NPr + 1];                     // this row's pexp entries of term t, two per LDS read
-            if constexpr (L.pairs) {
-                sfor<0, (NP + 1) / 2>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = 2 * decltype(jc)::value;
-                    const wv::pair_t v = wv::ld2(&Ms[L.pexpr + L.gat(t, j, 0, NP) + 2 * grow]);
-                    pe[j] = v.lo;
-                    pe[j + 1] = v.hi;
-                });
-            } else {
-                sfor<0, NP>([&](auto jc) ACME_LAMBDA { pe[decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + grow]; });
-            }
-            if constexpr (q0_in_pad) acc = pe[NP];
+            double acc = q0_in_pad ? pe[t][NP] : q0v[t];
             if constexpr (S::FUSE) {       // one statement per term; the first one waits for p (DPP hazard)
-                wv::fmac_bcast_chain<NP, t == 0 || S::CHAINWAIT>(acc, p, pe);
+                wv::fmac_bcast_chain<NP, t == 0 || S::CHAINWAIT>(acc, p, pe[t]);
             } else {
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    acc = fma(pe[j], pb[j], acc);
+                    acc = fma(pe[t][j], pb[j], acc);
                 });
             }
             pf[t] = acc;
-            wv::sched_fence();   // bound the number of LDS loads in flight (register pressure)
         });
     };
 
@@ -993,6 +976,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             });
             a[j] = acc;
         });
+        if constexpr (L.pairs && NN % 2 == 1) {
+            // the pad halves of the rows' last pairs, "used" here: dead on arrival, their registers were handed
+            // to the NEXT load of the batch -- which then had to wait for the whole batch before it could issue
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA { wv::touch(fqv[decltype(tc_)::value][NN]); });
+        }
         // Non-finite anywhere in this instance's res / J (src/solvers.jl:219-221: solve() returns at once)?  No
         // test of its own here: a NaN in res or J turns the elimination's result into NaN, an infinite residual
         // too (inf * 0), an infinite entry of J ends up as a pivot (the pivot search prefers it) whose stored
@@ -1268,11 +1256,16 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     d = fma(t, t, d);
                 });
             } else {   // cp_j - p_j as a fused broadcast multiply-add with -1 (exact), then the square
+                // (all the stored p's requested first: load - wait - use per column exposed the LDS latency
+                // np times a sample)
+                double cpv[NPr];
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { cpv[decltype(jc)::value] = cp[decltype(jc)::value * CACHE + (lig & (CACHE - 1))]; });
+                wv::sched_fence();
                 const double m1 = wv::keep(-1.0);
                 wv::dpp_wait();
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    double t = cp[j * CACHE + (lig & (CACHE - 1))];
+                    double t = cpv[j];
                     wv::fmac_bcast<j>(t, target, m1);
                     d = fma(t, t, d);
                 });
