@@ -912,6 +912,19 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 sfor<0, NN>([&](auto jc) ACME_LAMBDA { fqv[t][decltype(jc)::value] = Ms[L.fqr + L.gat(t, decltype(jc)::value, 0, NN) + grow]; });
             }
         });
+        // the row's 13 constants, staged in pairs (Shape::RCPAIR).  Small shapes request them HERE, with the fq
+        // rows: their q chains are too short to cover a second LDS round trip started behind them
+        double urc[14];
+        auto load_urc = [&]() ACME_LAMBDA {
+            sfor<0, 7>([&](auto pc) ACME_LAMBDA {
+                constexpr int p = decltype(pc)::value;
+                const wv::pair_t v = wv::ld2(&rd.rc[p * 2 * GROUP]);
+                urc[2 * p] = v.lo;
+                urc[2 * p + 1] = v.hi;
+            });
+        };
+        constexpr bool URC_FIRST = !S::RARE && NN < 7;       // (nn = 7, config 4's shape: -0.5 % with it, 19 registers already spilled)
+        if constexpr (URC_FIRST) load_urc();
         wv::sched_fence();
         double e[NT];
         if constexpr (!S::FUSE) {
@@ -943,13 +956,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             ACME_T2(TB_E2);
             eval_row<true, NT>(rd, e, exA, exB, res, tv);
         } else {
-            double urc[14];      // the row's 13 constants, staged in pairs (Shape::RCPAIR)
-            sfor<0, 7>([&](auto pc) ACME_LAMBDA {
-                constexpr int p = decltype(pc)::value;
-                const wv::pair_t v = wv::ld2(&rd.rc[p * 2 * GROUP]);
-                urc[2 * p] = v.lo;
-                urc[2 * p + 1] = v.hi;
-            });
+            if constexpr (!URC_FIRST) load_urc();
             const double sA = urc[0], sB = urc[1];
             // (EXP2: no branch at all -- a row without a second junction has sB = 0, and exp_junction2 returns
             // exactly 1 for it, as the other path sets it; a model without any BJT in one of these shapes
@@ -1007,12 +1014,18 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 if constexpr (j + 1 < NP) jp[j + 1] = a1;
             });
         } else {
+            double pv[NT][NPr];      // (all entries requested first: column by column, every column waited for its own reads)
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                sfor<0, NP>([&](auto jc) ACME_LAMBDA { pv[t][decltype(jc)::value] = Ms[L.pexpr + L.gat(t, decltype(jc)::value, 0, NP) + grow]; });
+            });
+            wv::sched_fence();
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                double acc = tv[0] * Ms[L.pexpr + L.gat(0, j, 0, NP) + grow];
+                double acc = tv[0] * pv[0][j];
                 sfor<1, NT>([&](auto tc_) ACME_LAMBDA {
                     constexpr int t = decltype(tc_)::value;
-                    acc = fma(tv[t], Ms[L.pexpr + L.gat(t, j, 0, NP) + grow], acc);
+                    acc = fma(tv[t], pv[t][j], acc);
                 });
                 jp[j] = acc;
             });
@@ -1169,8 +1182,9 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
     // returns hasconverged, leaves needediterations in `its`.
     auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
-        double mul[NN + 2];
+        double mul[NN + 2], oj[NPr];
         if constexpr (S::MULT) LU::template load_stored<S>(mul, ojp);     // requested first: needed last, ~60 instructions on
+        else if constexpr (NN < 7) sfor<0, NP>([&](auto jc) ACME_LAMBDA { oj[decltype(jc)::value] = ojp[decltype(jc)::value * OS]; });   // (likewise; nn = 7: no gain)
         set_p(target);
         // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215).  Row r of
         // last_Jp (p - last_p) is  sum_t Jq[r, tc_t] (pfull(p) - pfull(last_p))[tc_t]  (Jp = Jq pexp,
@@ -1195,7 +1209,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             const double dp = target - lp;
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
-                t = fma(ojp[j * OS], wv::bcast16<j>(dp), t);
+                t = fma(NN < 7 ? oj[j] : ojp[j * OS], wv::bcast16<j>(dp), t);
             });
         }
         z = sel(need, lz - t, z);
