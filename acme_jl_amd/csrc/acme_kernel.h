@@ -203,7 +203,6 @@ template <int I, class F> ACME_DEV void sfor_down(F &&f) {  // I-1 ... 0
 constexpr unsigned long long rows4(unsigned long long row16) { return (row16 & 0xFFFFull) * 0x0001000100010001ull; }
 template <int K> ACME_DEV bool lig_gt() { return wv::lanes(rows4(0xFFFFull << (K + 1))); }        // lig > K
 template <int K> ACME_DEV bool lig_eq() { return wv::lanes(rows4(1ull << K)); }                   // lig == K
-template <int K> ACME_DEV bool lig_lt() { return wv::lanes(rows4((1ull << K) - 1ull)); }          // lig < K
 template <int K, int N> ACME_DEV bool lig_in() {                                                 // K <= lig < N
     return wv::lanes(rows4(((1ull << N) - 1ull) & ~((1ull << K) - 1ull)));
 }

@@ -152,21 +152,6 @@ template <int N, int M> ACME_DEV void fmac_self_chain(double &acc, const double 
 
 // two wait states before a run of fmac_bcast statements whose source may have just been produced
 ACME_DEV void dpp_wait() { asm volatile("s_nop 1"); }
-// Pivot-lane bookkeeping of one elimination step, for the lanes of `mask` only (a wave-uniform
-// lane mask): dinv = inv, nlm = 0.  Two moves under a narrowed EXEC instead of four v_cndmask.
-// EXEC is written by SALU instructions here, which DPP instructions do not have to wait for.
-ACME_DEV void pivot_lane_moves(unsigned long long mask, double &dinv, double inv, double &nlm) {
-    unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_mov_b64 %[d], %[i]\n\tv_mov_b64 %[n], 0\n\ts_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save), [d] "+v"(dinv), [n] "+v"(nlm) : [m] "s"(mask), [i] "v"(inv) : "scc");
-}
-// next step's pivot-lane mask: one s_lshl_b64 on a live scalar pair instead of two s_mov_b32 of a
-// fresh 64-bit literal
-ACME_DEV unsigned long long mask_shl1(unsigned long long m) {
-    asm("s_lshl_b64 %0, %0, 1" : "+s"(m) : : "scc");
-    return m;
-}
-
 // The scalar head of one Gauss-Jordan step as ONE statement (the compiler brackets every inline-asm
 // statement with defensive s_nop's; fused, the step costs 14 issue slots instead of 20):
 //   piv  = row_newbcast:K of ak                       (pivot, to every lane of the row)

@@ -185,10 +185,6 @@ template <int I, int N, int OFF, int M> ACME_DEV void fmac_bcast_chain_(double &
 template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(double &acc, double src, const double (&mul)[M]) { fmac_bcast_chain_<0, N, OFF, M>(acc, src, mul); }
 ACME_DEV void dpp_wait() {}
 ACME_DEV bool lanes(unsigned long long mask);
-ACME_DEV void pivot_lane_moves(unsigned long long mask, double &dinv, double inv, double &nlm) {
-    if (lanes(mask)) { dinv = inv; nlm = 0.0; }
-}
-ACME_DEV unsigned long long mask_shl1(unsigned long long m) { return m << 1; }
 ACME_DEV double recip(double d);
 template <int K, bool SAFE>
 ACME_DEV void gj_step_head(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz) {
