@@ -220,10 +220,11 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     // evaluate!(nleq, z): res, Jq non-zeros tv, J = Jq fq -> jm.  Returns finite(res, J).
     auto evaluate = [&](const double (&zz)[NN]) ACME_LAMBDA -> bool {
         double chk = 0.0;
+        // q entries of every row first ...
+        double e[NN][NT];
         sfor<0, NN>([&](auto rc_) ACME_LAMBDA {
             constexpr int r = decltype(rc_)::value;
             const auto R = row_ptr(r * LL.row);
-            double e[NT];
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
                 double acc = pf[r][t];
@@ -231,29 +232,48 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                     constexpr int j = decltype(jc)::value;
                     acc = fma(R[LL.fq + t * NN + j], zz[j], acc);
                 });
-                e[t] = acc;
+                e[r][t] = acc;
             });
-            // unified element row (acme_common.h).  One scalar branch per row -- does the MODEL have a
-            // BJT, i.e. can a second exponential be needed -- as in the 16-lane kernel (rows without a
-            // junction have sA = sB = 0: exp(0) - 1 = 0); a branch per row KIND (the kinds are
-            // wave-uniform too) came out as four branches a row, ~30 cycles each with nothing to hide them
+        });
+        // ... then the exponentials of the unified element rows (acme_common.h), two at a time in lockstep
+        // (exp_junction2: the same arithmetic per argument as exp_junction, the two dependency chains interleaved
+        // -- a lone wave waits out every dependent fp64 instruction): with a BJT in the MODEL both junctions of a
+        // row (rows without a junction have sA = sB = 0: exp(0) - 1 = 0), without one the first junctions of two
+        // ROWS.  ONE scalar branch for all rows -- a branch per row, or per row KIND (the kinds are wave-uniform
+        // too), costs ~30 cycles each with nothing to hide them.
+        double exA[NN], exB[NN];
+        auto sa = [&](auto rc_) ACME_LAMBDA { return (row_ptr(decltype(rc_)::value * LL.row) + (LL.ur - UR_SA))[UR_SA]; };
+        auto sb = [&](auto rc_) ACME_LAMBDA { return (row_ptr(decltype(rc_)::value * LL.row) + (LL.ur - UR_SA))[UR_SB]; };
+        if (has_bjt) {
+            sfor<0, NN>([&](auto rc_) ACME_LAMBDA {
+                constexpr int r = decltype(rc_)::value;
+                exp_junction2(e[r][0] * sa(rc_), e[r][1] * sb(rc_), exA[r], exB[r], etab);
+            });
+        } else {
+            sfor<0, NN / 2>([&](auto pc) ACME_LAMBDA {
+                constexpr int r = 2 * decltype(pc)::value;
+                exp_junction2(e[r][0] * sa(std::integral_constant<int, r>{}), e[r + 1][0] * sa(std::integral_constant<int, r + 1>{}),
+                              exA[r], exA[r + 1], etab);
+            });
+            if constexpr (NN % 2 == 1) exA[NN - 1] = exp_junction<false>(e[NN - 1][0] * sa(std::integral_constant<int, NN - 1>{}), etab);
+            sfor<0, NN>([&](auto rc_) ACME_LAMBDA { exB[decltype(rc_)::value] = 1.0; });
+        }
+        sfor<0, NN>([&](auto rc_) ACME_LAMBDA {
+            constexpr int r = decltype(rc_)::value;
+            const auto R = row_ptr(r * LL.row);
             const auto U = R + (LL.ur - UR_SA);           // U[UR_x] = unified row constant x
-            const double sA = U[UR_SA], sB = U[UR_SB];
-            double exA, exB = 1.0;
-            if (has_bjt) exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etab);
-            else exA = exp_junction<false>(e[0] * sA, etab);
             const double cA = U[UR_CA], cB = U[UR_CB], dA = U[UR_DA], dB = U[UR_DB], h = U[UR_H];
             const double g0 = U[UR_G0], g1 = U[UR_G1], g2 = U[UR_G2], w0 = U[UR_W0], w1 = U[UR_W1];
-            const double hw = h * fma(w1, e[2], w0);
-            double rr = cA * (exA - 1.0);
-            rr = fma(cB, exB - 1.0, rr);
-            rr = fma(g0, e[0], rr);
-            rr = fma(g1, e[1], rr);
-            rr = fma(g2, e[2], rr);
-            res[r] = fma(hw, e[1], rr);
-            tv[r][0] = fma(dA, exA, g0);
-            tv[r][1] = fma(dB, exB, g1 + hw);
-            tv[r][2] = fma(h, e[1], g2);
+            const double hw = h * fma(w1, e[r][2], w0);
+            double rr = cA * (exA[r] - 1.0);
+            rr = fma(cB, exB[r] - 1.0, rr);
+            rr = fma(g0, e[r][0], rr);
+            rr = fma(g1, e[r][1], rr);
+            rr = fma(g2, e[r][2], rr);
+            res[r] = fma(hw, e[r][1], rr);
+            tv[r][0] = fma(dA, exA[r], g0);
+            tv[r][1] = fma(dB, exB[r], g1 + hw);
+            tv[r][2] = fma(h, e[r][1], g2);
             sfor<0, NN>([&](auto jc) ACME_LAMBDA {      // J row = Jq row * fq
                 constexpr int j = decltype(jc)::value;
                 double acc = tv[r][0] * R[LL.fq + 0 * NN + j];
