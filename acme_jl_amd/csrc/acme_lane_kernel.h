@@ -418,7 +418,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                 });
                 sfor<0, NN>([&](auto ic) ACME_LAMBDA {
                     constexpr int i = decltype(ic)::value;
-                    const double v = cag[S::CACHE1 + e * NN + i];
+                    const double v = cag[S::CACHEPM + e * NN + i];
                     lz[i] = hit ? v : lz[i];
                 });
                 // set_extrapolation_origin(base, p_c, z_c): re-linearise there; the other lanes keep
@@ -436,7 +436,7 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
                     if constexpr (CREG) sfor<0, CACHE>([&](auto ec) ACME_LAMBDA { cpr[j][decltype(ec)::value] = slot == decltype(ec)::value ? target[j] : cpr[j][decltype(ec)::value]; });
                     else cpl[(j * CACHE + slot) * LANE_BLOCK] = target[j];
                 });
-                sfor<0, NN>([&](auto ic) ACME_LAMBDA { cag[S::CACHE1 + slot * NN + decltype(ic)::value] = z[decltype(ic)::value]; });
+                sfor<0, NN>([&](auto ic) ACME_LAMBDA { cag[S::CACHEPM + slot * NN + decltype(ic)::value] = z[decltype(ic)::value]; });
                 chead = ccount < CACHE ? chead : (chead + 1) & (CACHE - 1);
                 ccount = ccount < CACHE ? ccount + 1 : ccount;
             }

@@ -313,7 +313,9 @@ def test_emulated_caching_solver(emu_lib):
     tolerance."""
     from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver
     from acme_jl_amd.runner import ModelRunner
-    for name, N, T in (("superover_var", 4, 450), ("birdie_var", 3, 600), ("diodeclipper", 3, 300)):
+    # one case per kernel family on the reference's default stack: 16-lane shared image (superover_var, birdie_var),
+    # lane-per-instance kernel with a zero (diodeclipper) and a non-zero (birdie_fixed) initial solution
+    for name, N, T in (("superover_var", 4, 450), ("birdie_var", 3, 600), ("diodeclipper", 3, 300), ("birdie_fixed", 4, 600)):
         m = load(name, CachingHomotopySolver)
         u = sweep_inputs(name, N, T)
         r = ModelRunner(m, N, lib=emu_lib)
@@ -555,3 +557,23 @@ def test_emulated_whole_wave_dead(emu_lib, name, lane, monkeypatch):
     r2.run(ub[:, :, :K + 1], check=False)
     assert np.array_equal(ra["iters_total"], r2.report_arrays()["iters_total"])
     assert (ra["iters_total"] >= its_ref).all()
+
+
+def test_emulated_lane_kernel_cache_layout(emu_lib, monkeypatch):
+    """The lane-per-instance kernel and the 16-lane kernels share ONE HBM layout of the solution cache
+    (cp | count, head | cz): after a lane-kernel run that stored solutions, solve(p = 0) through the 16-lane
+    solve kernel must hit the CachingSolver's initial entry (p = 0, z = init_z; src/solvers.jl:327-333) and
+    accept it as it stands -- one iteration, z == init_z.  (Round 3's lane kernel wrote its stored z's two
+    doubles low: entry 1 landed on entry 0.)"""
+    from acme_jl_amd.model import CachingHomotopySolver
+    monkeypatch.setenv("ACME_LANE_KERNEL", "1")
+    m = load("birdie_fixed", CachingHomotopySolver)
+    assert np.abs(m.subs[0].init_z).min() > 0.01
+    u = sweep_inputs("birdie_fixed", 4, 300)
+    r = emu_runner(emu_lib, m, 4)
+    r.run(u[:, :, :170])
+    r.run(u[:, :, 170:])
+    assert (r.report_arrays()["iters_max"] > 5).sum() >= 2      # something was stored
+    z, conv, its = r.solve(np.zeros((4, 2)))
+    assert conv.all() and its.tolist() == [1, 1, 1, 1]
+    assert np.array_equal(z, np.tile(m.subs[0].init_z, (4, 1)))

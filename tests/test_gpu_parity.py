@@ -649,3 +649,26 @@ def test_whole_wave_dead(hip_lib, name, lane, monkeypatch):
     r2 = runner(hip_lib, m, N)
     r2.run(ub[:, :, :K + 1], check=False)
     assert np.array_equal(ra["iters_total"], r2.report_arrays()["iters_total"])
+
+
+@pytest.mark.gpu
+def test_lane_kernel_cache_layout(hip_lib, monkeypatch):
+    """Lane-per-instance kernel and 16-lane kernels share one HBM layout of the solution cache: after a
+    lane-kernel run that stored solutions (several launches, more stores than the cache holds), solve(p = 0)
+    through the 16-lane solve kernel hits the initial entry (p = 0, z = init_z; src/solvers.jl:327-333) and
+    accepts it as it stands; and the run itself follows the oracle's bounded store."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    monkeypatch.setenv("ACME_LANE_KERNEL", "1")
+    m = load("birdie_fixed", CachingHomotopySolver)
+    N, T = 64, 1200
+    u = sweep_inputs("birdie_fixed", N, T)
+    r = ModelRunner(m, N, lib=hip_lib)
+    y = np.concatenate([r.run(u[:, :, a:b]) for a, b in ((0, 300), (300, 555), (555, T))], axis=2)
+    yref, its = oracle_run(m, u, cache_limit=16)
+    assert_close(y, yref)
+    got = r.report_arrays()["iters_total"]
+    assert np.abs(got - its).max() <= max(3, 0.01 * its.max()), (got, its)
+    z, conv, it1 = r.solve(np.zeros((N, 2)))
+    assert conv.all() and (it1 == 1).all()
+    assert np.array_equal(z, np.tile(m.subs[0].init_z, (N, 1)))
