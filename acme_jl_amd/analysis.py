@@ -98,7 +98,7 @@ def steadystate_(runner, u=None):
     return X
 
 
-def linearize(model, usteady=None, lib=None, device=None, reference_offsets=True):
+def linearize(model, usteady=None, lib=None, device=None, reference_offsets=None):
     """``linearize(model, usteady)`` (src/ACME.jl:505-550, src/solvers.jl:407-414): the small-signal
     linear ``DiscreteModel`` around the steady state for the constant input ``usteady``.
 
@@ -117,6 +117,14 @@ def linearize(model, usteady=None, lib=None, device=None, reference_offsets=True
     single-sub-problem models, where the two forms coincide).  ``reference_offsets=False`` carries the
     offsets through, which makes decomposed and non-decomposed derivations of one circuit agree to
     rounding."""
+    if reference_offsets is None:
+        reference_offsets = True
+        if len(model.subs) > 1:
+            import warnings
+            warnings.warn("linearize: model has several nonlinear sub-problems; the reference's constant terms "
+                          "(src/ACME.jl:534,538) are reproduced literally and miss the operating point -- pass "
+                          "reference_offsets=False to carry the earlier sub-problems' offsets through",
+                          stacklevel=2)
     u = np.zeros(model.nu) if usteady is None else np.asarray(usteady, dtype=np.float64)
     xs = steadystate(model, u, lib=lib, device=device)
     x0, a, b = model.x0.copy(), model.a.copy(), model.b.copy()
