@@ -51,6 +51,10 @@ struct Dims {
     int nn, nq, np, nx, nu, ny;
     int rare;  // shape compiled with / model needs the MOSFET, tanh op-amp, JA kinds
     int nsub;  // nonlinear sub-problems (shape: capacity; model: actual count)
+    // residual rows that are LINEAR in z for a given p -- potentiometer halves whose position comes from an input
+    // only (src/elements.jl:25-30) -- and are condensed out of the Newton system (acme_kernel.h "condensed solve";
+    // shape: the kernel is built for exactly this many; 0: none)
+    int nl;
 };
 
 // offsets (in doubles) of each matrix inside a model image
@@ -213,6 +217,11 @@ struct KArgs {
     double *jac_out;         // MODE_JAC kernels: [n_inst][np_io][nn_io] = -(J \ Jp) at the origin of solve_sub
     int solve_sub;           // sub-problem acme_batch_solve / the Jacobian export addresses
     int nsub;                // actual number of sub-problems (<= the shape's NSUB)
+    // condensed shapes (Dims::nl > 0) keep z in a PERMUTED basis (the linear rows' pivot columns first, acme_pack.h):
+    // zperm[i] = the caller's index of the kernel's z_i (identity otherwise); z_out / jac_out are written through it
+    int zperm[GROUP];
+    int *cflags;             // [n_inst]: bit 0 = the extrapolation origin may lie OFF the linear rows' subspace
+                             // (initial solution, acme_batch_set_state, an iterate accepted without a Newton step)
 };
 
 }  // namespace acme

@@ -52,7 +52,7 @@ template <class S> static KernelEntry make_entry(int index) {
     if (!(acme_shape_fns_part0(index, &f) || acme_shape_fns_part1(index, &f) || acme_shape_fns_part2(index, &f) ||
           acme_shape_fns_part3(index, &f)))
         abort();
-    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB}, f.lds, f.low, f.fn_lane,
+    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB, S::NL}, f.lds, f.low, f.fn_lane,
                        S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
                        lane_lds<S>(false), lane_lds<S>(true), f.launch_lane};
 }
@@ -61,7 +61,7 @@ static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = [] {
         std::vector<KernelEntry> v;
         int index = 0;
-#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub) v.push_back(make_entry<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(index++));
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub, nl) v.push_back(make_entry<Shape<nn, nq, np, nx, nu, ny, rare, nsub, nl>>(index++));
         ACME_SHAPES(ACME_X)
 #undef ACME_X
         return v;
@@ -71,7 +71,7 @@ static const std::vector<KernelEntry> &kernel_table() {
 
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
-        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub)
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub && k.d.nl == d.nl)
             return &k;
     return nullptr;
 }

@@ -42,8 +42,14 @@
 
 namespace acme {
 
-template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, int NSUB_ = 1> struct Shape {
+template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, int NSUB_ = 1, int NL_ = 0> struct Shape {
     static constexpr int NN = NN_, NQ = NQ_, NP = NP_, NX = NX_, NU = NU_, NY = NY_;
+    // NL: residual rows that are linear in z for a given p (potentiometer halves; acme_pack.h CondPlan), held by
+    // lanes 0 .. NL-1 and CONDENSED out of the Newton system, which then has NR = NN - NL unknowns (z_NL .. z_NN-1;
+    // the host permutes the z basis so that the linear rows' pivot columns come first): wave_main "condensed solve"
+    static constexpr int NL = NL_, NR = NN_ - NL_;
+    static constexpr bool COND = NL_ > 0;
+    static constexpr int NE = COND ? NR : NN;      // steps of the elimination the Newton loop runs (and records)
     // NSUB: capacity for nonlinear sub-problems solved one after another each sample
     // (src/ACME.jl:675-697); every sub-problem is padded to (NN, NQ, NP)
     static constexpr int NSUB = NN_ > 0 ? NSUB_ : 0;
@@ -135,8 +141,10 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // registers back -- headline +1.5 %, config 4 +2.0 % (with 8 spilled registers), birdie +3.3 %
     static constexpr bool EXPV = !RARE;
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
-    static constexpr int OS_MUL = 0, OS_DINV = NN, OS_TV = NN + 1, OS_PF = NN + 1 + NT;
-    static constexpr int OSLOTS = MULT ? (NN + 1 + 2 * NT + 1) & ~1 : NP;
+    static constexpr int OS_MUL = 0, OS_DINV = NE, OS_TV = NE + 1, OS_PF = NE + 1 + NT;
+    static constexpr int OSLOTS = MULT ? (NE + 1 + 2 * NT + 1) & ~1 : NP;
+    static_assert(!COND || (MULT && NSUB_ == 1 && RARE_ == 0 && NN_ >= 8 && NN_ < GROUP && NL_ < NN_ && NL_ <= 8 && NR <= 13 && NR % 2 == 1),
+                  "condensed shapes: one sub-problem of unified rows in the pair layout, row 15 free for the linear lanes' constants");
     static constexpr int ORIGIN1 = OSLOTS * OSTRIDE;          // one sub-problem
     // offset of slot s from the lane's position in the slab.  MULT: slots in PAIRS (two per
     // ds_read_b128 when the extrapolation reads them back), a lane's position counts double
@@ -430,6 +438,94 @@ template <int NN> struct RowLU {
         b *= mul[NN];
     }
 
+    // ---- condensed shapes: the same elimination in two RANGES of steps ---------------------------------
+    // Steps K0 .. K1-1 of the Gauss-Jordan elimination above (pivot rows in the lanes K0 .. K1-1, pivot columns of
+    // the same numbers) on a row of NN entries: every entry right of the pivot column is updated -- the columns
+    // K1 .. NN-1 ride along as augmented columns -- and so does every lane, whether its row belongs to the range or
+    // not.  The condensed shapes run the elimination of a Jacobian whose rows 0 .. NL-1 do not depend on z in two
+    // parts: <0, NL> once per change of the potentiometer positions (wave_main: condense) and <NL, NN> in the
+    // Newton loop, with the lanes 0 .. NL-1 riding along (their multipliers are not subject to the pivot
+    // threshold: those rows are "above the pivot").  STORE: as in solve_inplace, K1 - K0 multipliers and 1 / pivot.
+    template <int K0, int K1, int NC, bool STORE, class SH>
+    static ACME_DEV unsigned long long solve_range(double (&a)[NN > 0 ? NN : 1], double &b, double (&c)[NC > 0 ? NC : 1],
+                                                   double *slab, bool keep, double &dinv_out) {
+        constexpr int KN = K1 - K0;
+        static_assert(K0 >= 0 && K1 <= NN && KN >= 1 && (!STORE || (KN + 1) % 2 == 0), "");
+        double dinv = 1.0;
+        double rec[STORE ? KN + 1 : 1];
+        unsigned long long pivlanes = rows4(1ull << K0);
+        double vmx = 0.0, frz = 0.0;
+        sfor<K0, K1>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = decltype(kc)::value;
+            constexpr bool far_enough = k > K0 && (NN - k + NC >= 2);
+            constexpr int CNT = NN - 1 - k + 1 + NC;
+            double nlm;
+            double *rp[CNT];
+            sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA { rp[decltype(jc)::value - k - 1] = &a[decltype(jc)::value]; });
+            rp[NN - 1 - k] = &b;
+            sfor<0, NC>([&](auto jc) ACME_LAMBDA { rp[NN - k + decltype(jc)::value] = &c[decltype(jc)::value]; });
+            wv::gj_step<k, CNT, !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz, rp);
+            if constexpr (STORE) rec[k - K0] = nlm;
+        });
+        b *= dinv;
+        sfor<0, NC>([&](auto jc) ACME_LAMBDA { c[decltype(jc)::value] *= dinv; });
+        dinv_out = dinv;
+        if constexpr (STORE) {
+            rec[KN] = dinv;
+            if (keep)
+                sfor<0, (KN + 1) / 2>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = 2 * decltype(kc)::value;
+                    wv::st2(&slab[SH::oslot(k)], rec[k], rec[k + 1]);
+                });
+        }
+        const unsigned long long bad = wv::ballot(!(b * 0.0 == 0.0)) | wv::ballot(dinv == 0.0);
+        return wv::ballot(frz > PIVOT_THRESHOLD) | bad;
+    }
+    // the recorded steps of lanes K0 .. K0 + KN - 1 applied to another right-hand side (mul: KN multipliers, 1 / pivot)
+    template <int KN, class SH> static ACME_DEV void load_stored_n(double (&mul)[KN + 1], const double *slab) {
+        static_assert((KN + 1) % 2 == 0, "");
+        sfor<0, (KN + 1) / 2>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = 2 * decltype(kc)::value;
+            const wv::pair_t v = wv::ld2(&slab[SH::oslot(k)]);
+            mul[k] = v.lo;
+            mul[k + 1] = v.hi;
+        });
+    }
+    template <int K0, int KN> static ACME_DEV void apply_loaded_from(double &b, const double (&mul)[KN + 1]) {
+        wv::fmac_self_chain_from<K0, KN>(b, mul);
+        b *= mul[KN];
+    }
+    // pivot_order (below) restricted to the rows / columns K0 .. K1-1: the other lanes keep their rows
+    template <int K0, int K1> static ACME_DEV bool pivot_order_range(double (&a)[NN > 0 ? NN : 1], int &orig, int lig, int grp) {
+        bool ok = true;
+        orig = lig;
+        sfor<K0, K1>([&](auto kc) ACME_LAMBDA {
+            constexpr int k = decltype(kc)::value;
+            const bool in_k = wv::lanes_here<((1u << K1) - 1u) & ~((1u << k) - 1u)>();
+            const bool eq_k = wv::lanes_here<1u << k>();
+            const bool gt_k = wv::lanes_here<((1u << K1) - 1u) & ~((2u << k) - 1u)>();
+            double v = in_k ? fabs(a[k]) : -1.0;
+            double m = wv::allmax16(v);
+            unsigned long long bal = wv::ballot(v == m);
+            int msk = (int)((bal >> (grp * GROUP)) & (unsigned long long)(((1u << K1) - 1u) & ~((1u << k) - 1u)));
+            int kp = msk ? wv::ffs32(msk) - 1 : k;          // first row holding the maximum (all NaN: no interchange)
+            int src = eq_k ? kp : ((lig == kp) ? k : lig);   // interchange rows k <-> kp
+            sfor<k, K1>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                a[j] = wv::shfl16(a[j], src);
+            });
+            orig = wv::shfl16(orig, src);
+            double piv = wv::bcast16<k>(a[k]);
+            ok = ok && (piv != 0.0);
+            double lm = gt_k ? a[k] * wv::recip(piv) : 0.0;
+            sfor<k + 1, K1>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                a[j] = fma(-lm, wv::bcast16<k>(a[j]), a[j]);
+            });
+        });
+        return ok;
+    }
+
     // setlhs! with partial pivoting (first strict maximum, src/solvers.jl:58-78), run only to
     // LEARN the pivot order when solve_inplace reported a violation (a few % of the solves):
     // `orig` returns the original row now stored in this lane (the composed row interchanges);
@@ -673,6 +769,10 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                   NXSr = NXS > 0 ? NXS : 1;
     constexpr Layout L = S::L;
     using LU = RowLU<NN>;
+    // condensed solve (Shape::NL > 0): everything but the Jacobian export, which keeps the full system
+    constexpr bool COND = S::COND && MODE != MODE_JAC;
+    constexpr int NL = S::NL, NR = S::NR, NRr = COND ? NR : 1, NLr = COND ? NL : 1;
+    using LUL = RowLU<COND ? NL : 1>;       // the NL x NL block of the linear rows
 
     const int tid = wv::tid();
     const int lane = tid & 63, wave = tid >> 6;
@@ -763,11 +863,15 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     int grow_ = lig;     // ... and its row in the row-gathered copies (lanes beyond NN: the all-zero row, Layout::gs;
 #define grow (*(L.gs == GROUP ? &rowid : &grow_))      /* the same number when the copies have 16 rows */
     RowDesc rd;
+    const double *rc_norm = nullptr;
     auto load_rowdesc = [&]() ACME_LAMBDA {
         rd.kind = (lig < NN) ? rowi_s[0 * GROUP + rowid] : RK_NONE;
         rd.erow = rowi_s[1 * GROUP + rowid];
         rd.flags = rowi_s[2 * GROUP + rowid];
         rd.rc = rowc_s + (S::RCPAIR ? 2 : 1) * rowid;            // rc[c * GROUP] = row constant RC0 + c (RCPAIR: pair c at rc[c * 2 * GROUP])
+        // condensed shapes: in the Newton loop the lanes of the linear rows evaluate the constants of row 15 --
+        // res = e0, Jq = (1, 0, 0) (acme_pack.h) -- whatever row they hold
+        if constexpr (COND) rc_norm = lig < NL ? rowc_s + 2 * (GROUP - 1) : rd.rc;
         if constexpr (L.gs != GROUP) grow = lig < NN ? rowid : NN;
         // register-cached constants: the kind-by-kind evaluation (RARE shapes) wants rc[0..7],
         // the unified rows sA sB cA cB dA dB h
@@ -796,6 +900,20 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // (src/solvers.jl:209-215) needs
     double z = 0.0;      // current iterate z[lig]
     double pf[NT];       // (q0 + pexp*p) at the q rows rd.tc[] of this lane's residual row
+    // ---- condensed solve: state (see "condensed solve" below) ----------------------------------------------------
+    // cd: the CONDENSATION for the potentiometer positions cpos -- lanes NL .. NN-1: the rows of
+    // fq' = fq_N - fq_L W their residual row reads (term t, reduced unknown j); lanes 0 .. NL-1: cd[0] = their row of
+    // W = A_LL^-1 A_LN, cd[1][0 .. NL-1] = their row of A_LL^-1.  In registers for the whole launch, rewritten only
+    // when a potentiometer moves.
+    double cd[3][NRr];
+    double crw = 0.0;                 // lanes < NL: -r w of the row (res = v + crw i), for cpos
+    double cpos = (double)NAN;        // lanes < NL: the position the condensation was made for (NaN: none yet)
+    double pfr[NT];                   // pf' = pfull + fq_L zp_L at this lane's q rows (lanes < NL: pfr[0] = -zp_L)
+    double pft[NT];                   // pfull of the solve's target, parked while the origin has its turn (cached_solve)
+    sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pft[decltype(tc_)::value] = 0.0; });
+    if constexpr (COND)
+        sfor<0, 3>([&](auto tc_) ACME_LAMBDA { sfor<0, NR>([&](auto jc) ACME_LAMBDA { cd[decltype(tc_)::value][decltype(jc)::value] = 0.0; }); });
+    sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pfr[decltype(tc_)::value] = 0.0; });
     // per-row results of the latest evaluate!
     double a[NNr];       // J row -> LU row
     double res = 0.0;
@@ -1040,7 +1158,193 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             tv[t] = wv::shfl16(tv[t], orig);
             pf[t] = wv::shfl16(pf[t], orig);
         });
+        if constexpr (COND) {       // the row's reduced pfull entries and its rows of the condensation move along
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                pfr[decltype(tc_)::value] = wv::shfl16(pfr[decltype(tc_)::value], orig);
+                pft[decltype(tc_)::value] = wv::shfl16(pft[decltype(tc_)::value], orig);
+            });
+            sfor<0, 3>([&](auto tc_) ACME_LAMBDA {
+                sfor<0, NR>([&](auto jc) ACME_LAMBDA { cd[decltype(tc_)::value][decltype(jc)::value] = wv::shfl16(cd[decltype(tc_)::value][decltype(jc)::value], orig); });
+            });
+            crw = wv::shfl16(crw, orig);
+            cpos = wv::shfl16(cpos, orig);
+        }
         load_rowdesc();
+    };
+
+    int stale = 1;       // (an integer in a vector register, like the loop flags of base_solve; see linearize)
+    // ======================= condensed solve (Shape::NL > 0) ===========================================================
+    // The residual rows of a potentiometer,  res = v - r w i  with w = pos or 1 - pos  (src/elements.jl:25-30), are LINEAR
+    // in z for a given p when `pos` comes from the inputs alone (its fq row is zero, src/ACME.jl:176-189):
+    //     A_L(pos) z + b_L(p) = 0,    A_L = fq[v] - r w fq[i],    b_L = pfull[v] - r w pfull[i].
+    // The reference's Newton iteration (src/solvers.jl:207-236) solves these rows exactly in its first step and keeps
+    // them solved: all it iterates on are the other NR = NN - NL rows.  With the linear rows in lanes 0 .. NL-1 and
+    // their pivot columns first (acme_pack.h: CondPlan), z = (z_L, z_N):
+    //     z_L = zp_L - W z_N,   W = A_LL^-1 A_LN,   zp_L = -A_LL^-1 b_L
+    //     q = pfull + fq z = pf' + fq' z_N,   pf' = pfull + fq_L zp_L,   fq' = fq_N - fq_L W        (condensation)
+    // and the Jacobian of the reduced system,  S = Jq_N fq',  is the Schur complement the full elimination reaches
+    // after its first NL steps when it takes its pivots from the linear rows -- so the Newton loop forms S directly
+    // (NT x NR multiply-adds instead of NT x NN, twice) and eliminates NR steps instead of NN; the lanes of the linear
+    // rows ride along with their row of W (they evaluate the constants of row 15: res = e0 = -(zp_L - W z_N),
+    // Jq = (1, 0, 0)), so that the same elimination hands them -z_L of the new iterate: z_L never needs a pass of
+    // its own.  W, A_LL^-1 and fq' depend on the potentiometer positions only: `condense` recomputes them (Gauss-Jordan
+    // of the linear rows with the others riding along) when a position changes -- never, in a sweep with fixed pots --
+    // and they live in registers (cd) in between.  Same Newton iterates as the reference's, to rounding
+    // (tools/condense_proto.py compares the algebra with the oracle: identical iteration counts, outputs to 1e-14).
+    // An iterate OFF the subspace of the linear rows -- the extrapolated start when the origin was not on it: initial
+    // solution, acme_batch_set_state, or after a potentiometer moved -- is evaluated on the full q (`off`), its linear
+    // residuals take part in the convergence test, and the step lands on the subspace as the reference's does:
+    //     S dz_N = F_N - Jq_N (q - q'),   q' = pf' + fq' z_N.
+    const bool islin = COND && lig < NL;
+    const double sgn = islin ? 0.0 : 1.0;          // z <- sgn z - dz: the lanes of the linear rows get -dz = the new z_L
+    int osub = 1;                                  // the origin (lp, lz) may lie off the subspace (KArgs::cflags)
+    if constexpr (COND) osub = valid ? (A.cflags[inst] & 1) : 0;
+    double opos = (double)NAN;                     // lanes < NL: the potentiometer position at the origin (lp, lz)
+    double rhs = 0.0, lres = 0.0, efl1 = 0.0;
+    auto inst_any = [&](bool x) ACME_LAMBDA -> bool { return ((wv::ballot(x) >> (grp * GROUP)) & 0xFFFFull) != 0ull; };
+    // the rows' fq entries (two columns per LDS read), as in evaluate
+    auto load_fq_rows = [&](double (&fqv)[NT][NNr + 1]) ACME_LAMBDA {
+        sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+            constexpr int t = decltype(tc_)::value;
+            sfor<0, (NN + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = 2 * decltype(jc)::value;
+                const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * grow]);
+                fqv[t][j] = v.lo;
+                fqv[t][j + 1] = v.hi;
+            });
+        });
+    };
+    // W, A_LL^-1 and fq' for the potentiometer positions of the pfull entries set_p has just formed, for the instances
+    // with `upd`.  The linear rows keep the order the lanes have adopted for them unless a pivot fails the threshold
+    // (then: the reference's partial pivoting among them, once).
+    auto condense = [&](bool upd) ACME_LAMBDA {
+        if constexpr (COND) {
+            double fqv[NT][NNr + 1], al[NNr], c6[NLr], hw = 0.0;
+            int tries = 0;
+            for (;;) {
+                tries = wv::opaque(tries);
+                load_fq_rows(fqv);
+                // A_L row = Jq row * fq of a potentiometer half: (g0, h w, .) (acme_common.h: UnifiedRowConst)
+                const wv::pair_t h_ = wv::ld2(&rd.rc[3 * 2 * GROUP]), g01 = wv::ld2(&rd.rc[4 * 2 * GROUP]),
+                                 g2w0 = wv::ld2(&rd.rc[5 * 2 * GROUP]), w1_ = wv::ld2(&rd.rc[6 * 2 * GROUP]);
+                hw = h_.lo * fma(w1_.lo, pf[2], g2w0.hi);
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    al[j] = fma(hw, fqv[1][j], g01.lo * fqv[0][j]);
+                });
+                // A_LL^-1 (rows in the lanes): Gauss-Jordan of [A_LL | I]
+                double a6[NLr], b6 = 0.0, d6;
+                sfor<0, NL>([&](auto kc) ACME_LAMBDA {
+                    constexpr int k = decltype(kc)::value;
+                    a6[k] = al[k];
+                    c6[k] = lig_eq<k>() ? 1.0 : 0.0;
+                });
+                unsigned long long viol = LUL::template solve_inplace<NL, false, S, true, true>(a6, b6, c6, nullptr, false, d6);
+                viol &= wv::ballot(islin && upd);
+                if (ACME_USUAL(viol == 0ull || tries != 0)) break;
+                const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
+                sfor<0, NL>([&](auto kc) ACME_LAMBDA { a6[decltype(kc)::value] = al[decltype(kc)::value]; });
+                int orig;
+                (void)LUL::template pivot_order_range<0, NL>(a6, orig, lig, grp);
+                orig = (mine && islin) ? orig : lig;
+                adopt(orig);
+                stale = mine ? 1 : stale;       // the slab's entries of these lanes belong to the rows they held
+                tries = 1;
+            }
+            // W (lanes < NL) and fq' (the others, one pass per term of their rows): the elimination of the linear rows
+            // with every row's columns NL .. NN-1 riding along
+            double nd[3][NRr];
+            sfor<0, 3>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                double a_[NNr], b_ = 0.0, none[1] = {0.0}, dv;
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a_[decltype(jc)::value] = islin ? al[decltype(jc)::value] : fqv[t][decltype(jc)::value]; });
+                (void)LU::template solve_range<0, NL, 0, false, S>(a_, b_, none, nullptr, false, dv);
+                sfor<0, NR>([&](auto jc) ACME_LAMBDA { nd[t][decltype(jc)::value] = islin ? a_[NL + decltype(jc)::value] * dv : a_[NL + decltype(jc)::value]; });
+            });
+            sfor<0, NR>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                const double l1 = j < NL ? c6[j < NL ? j : 0] : 0.0;
+                cd[0][j] = upd ? nd[0][j] : cd[0][j];
+                cd[1][j] = upd ? (islin ? l1 : nd[1][j]) : cd[1][j];
+                cd[2][j] = upd ? (islin ? 0.0 : nd[2][j]) : cd[2][j];
+            });
+            crw = upd ? hw : crw;
+            cpos = upd ? pf[2] : cpos;
+        }
+    };
+    // pf (set_p) -> pf' for the current condensation; lanes < NL: pfr[0] = -zp_L = A_LL^-1 b_L
+    auto prep_reduced = [&]() ACME_LAMBDA {
+        if constexpr (COND) {
+            double fql[NT][NLr + 1];       // fq_L entries of this lane's rows: the first NL columns of the row-gathered copies
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                sfor<0, (NL + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * grow]);
+                    fql[t][j] = v.lo;
+                    fql[t][j + 1] = v.hi;
+                });
+            });
+            const double bl = fma(crw, pf[1], pf[0]);
+            double nzp = 0.0;
+            wv::fmac_bcast_chain<NL, true>(nzp, bl, cd[1]);
+            const double zpl = -nzp;
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                pfr[t] = pf[t];
+                wv::fmac_bcast_chain<NL, true>(pfr[t], zpl, fql[t]);      // (every statement waits: they are not ordered among themselves)
+            });
+            pfr[0] = islin ? nzp : pfr[0];
+        }
+    };
+    // evaluate! on the reduced system: q' = pf' + fq' z_N, (res, Jq) = elements(q'), S row = Jq row * fq'.  Leaves the S row
+    // in a[NL ..], the residual in res, the right-hand side of the elimination in rhs.  off (offany: any instance of the
+    // wave): this iterate may lie off the linear rows' subspace -- the elements see the full q = pfull + fq z, the step
+    // corrects for the difference, and lres is the lane's linear residual (lanes < NL).
+    auto evaluate_c = [&](double zz, bool offany, bool off) ACME_LAMBDA {
+        if constexpr (COND) {
+            double urc[14];
+            sfor<0, 7>([&](auto pc) ACME_LAMBDA {
+                constexpr int p = decltype(pc)::value;
+                const wv::pair_t v = wv::ld2(&rc_norm[p * 2 * GROUP]);
+                urc[2 * p] = v.lo;
+                urc[2 * p + 1] = v.hi;
+            });
+            double e[NT], ef[NT], eu[NT];
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pfr[decltype(tc_)::value]; });
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                wv::fmac_bcast_chain_from<NL, NR, t == 0>(e[t], zz, cd[t]);
+            });
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA { ef[decltype(tc_)::value] = eu[decltype(tc_)::value] = e[decltype(tc_)::value]; });
+            if (ACME_RARE(offany)) {
+                double fqv[NT][NNr + 1];
+                load_fq_rows(fqv);
+                sfor<0, NT>([&](auto tc_) ACME_LAMBDA { ef[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
+                sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                    constexpr int t = decltype(tc_)::value;
+                    wv::fmac_bcast_chain<NN, true>(ef[t], zz, fqv[t]);
+                });
+                sfor<0, NT>([&](auto tc_) ACME_LAMBDA { eu[decltype(tc_)::value] = (off && !islin) ? ef[decltype(tc_)::value] : e[decltype(tc_)::value]; });
+            }
+            double exA, exB;
+            exp_junction2(eu[0] * urc[0], eu[1] * urc[1], exA, exB, etv);
+            eval_row_unified_c<NT>(urc, eu, exA, exB, res, tv);
+            sfor<0, NR>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                double acc = tv[0] * cd[0][j];
+                sfor<1, NT>([&](auto tc_) ACME_LAMBDA { acc = fma(tv[decltype(tc_)::value], cd[decltype(tc_)::value][j], acc); });
+                a[NL + j] = acc;
+            });
+            rhs = res;
+            if (ACME_RARE(offany)) {
+                double corr = 0.0;
+                sfor<0, NT>([&](auto tc_) ACME_LAMBDA { corr = fma(tv[decltype(tc_)::value], ef[decltype(tc_)::value] - e[decltype(tc_)::value], corr); });
+                rhs = (off && !islin) ? res - corr : res;
+                lres = fma(crw, ef[1], ef[0]);
+                efl1 = ef[1];
+            }
+        }
     };
 
     // One Newton linearisation at z: evaluate! (res, J), then solve J dz = res by in-place
@@ -1059,9 +1363,10 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // `stale`: the slab no longer describes the origin (lp, lz) in the lanes' current order -- an
     // instance changed its row order without storing a new origin, or a recorded elimination was
     // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
-    int stale = 1;       // (an integer in a vector register, like the loop flags of base_solve)
     // (actm: the caller's ballot of `act` -- it has it anyway, as its loop condition)
-    auto linearize = [&](double zz, bool act, unsigned long long actm, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
+    // (condensed shapes: offany / off -- this iterate may lie off the linear rows' subspace, see evaluate_c)
+    auto linearize = [&](double zz, bool act, unsigned long long actm, bool force, bool &finite, bool &ok, bool &small, double &dz,
+                         bool offany = false, bool off = false) ACME_LAMBDA {
         int okf = 1;     // `ok`: carried as an integer in a vector register
         bool want, recording, mine;
         double jp[NPr];
@@ -1071,14 +1376,18 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         auto eliminate = [&]() ACME_LAMBDA -> unsigned long long {
             // only the boolean is needed, so no max-reduction -- one compare and a ballot; a NaN
             // residual counts as not small
-            const unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4((1ull << NN) - 1ull);
+            unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4(((1ull << NN) - 1ull) & ~((1ull << (COND ? NL : 0)) - 1ull));
+            if constexpr (COND)         // (the linear rows count where the iterate may be off their subspace)
+                if (ACME_RARE(offany)) big |= wv::ballot(off && islin && !(fabs(lres) < tol_v));
             small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
             want = force || (act && finite && small);
             unsigned long long viol;
             double none[1] = {0.0};
-            dz = res;
+            dz = COND ? rhs : res;
             recording = wv::ballot(want) != 0ull;
-            if constexpr (S::MULT) {
+            if constexpr (COND) {
+                viol = LU::template solve_range<NL, NN, 0, true, S>(a, dz, none, ojp, want && lig < NN, dinv);
+            } else if constexpr (S::MULT) {
                 // ONE elimination for iterates that become the origin and for those that do not: the recording
                 // costs no arithmetic (the multipliers exist anyway), only the predicated stores at its end
                 viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN), dinv);
@@ -1100,22 +1409,27 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             return viol;
         };
         // The usual pass, as straight-line code (no phase variable, no loop head to copy registers at) ...
-        finite = evaluate(zz);
+        if constexpr (COND) { evaluate_c(zz, offany, off); finite = true; }
+        else finite = evaluate(zz);
         ACME_T(TB_EVAL);
         if (ACME_RARE(eliminate() != 0ull)) {
             // ... and the rare one: some instance of the wave has to re-learn its pivot order.  Only the
             // instances that tripped the threshold change their row order: what an instance computes must
             // not depend on which other instances share its wave.
             const bool relearn = mine;
-            (void)evaluate(zz);                  // J once more (the elimination has consumed it)
+            if constexpr (COND) evaluate_c(zz, offany, off);
+            else (void)evaluate(zz);                  // J once more (the elimination has consumed it)
             int orig;
-            const bool okp = LU::pivot_order(a, orig, lig, grp);
+            bool okp;
+            if constexpr (COND) okp = LU::template pivot_order_range<NL, NN>(a, orig, lig, grp);     // (the reduced system's rows only)
+            else okp = LU::pivot_order(a, orig, lig, grp);
             okf = relearn ? (okp ? 1 : 0) : 1;
             orig = relearn ? orig : lig;
             adopt(orig);
             if constexpr (S::MULT) stale = relearn ? 1 : stale;   // the recorded elimination is per row order
             ACME_T(TB_PIVOT);
-            finite = evaluate(zz);               // ... in the new row order
+            if constexpr (COND) evaluate_c(zz, offany, off);
+            else finite = evaluate(zz);               // ... in the new row order
             (void)eliminate();
         }
         okf = mine ? 0 : okf;
@@ -1124,13 +1438,13 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 if constexpr (S::MULT) {
                     // the rest of the entry -- the row's Jq non-zeros and pfull entries -- as 16-byte pairs
                     // too (the multipliers and 1/pivot went in at the end of the elimination)
-                    sfor<(NN + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
+                    sfor<(S::NE + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
                         constexpr int c = 2 * decltype(cc)::value;
                         auto slotv = [&](auto sc) ACME_LAMBDA -> double {
                             constexpr int sl = decltype(sc)::value;
-                            if constexpr (sl == NN) return dinv;
+                            if constexpr (sl == S::OS_DINV) return dinv;
                             else if constexpr (sl < S::OS_TV + NT) return tv[sl - S::OS_TV];
-                            else if constexpr (sl < S::OS_PF + NT) return pf[sl - S::OS_PF];
+                            else if constexpr (sl < S::OS_PF + NT) return COND ? pfr[sl - S::OS_PF] : pf[sl - S::OS_PF];
                             else return 0.0;
                         };
                         wv::st2(&ojp[S::oslot(c)], slotv(std::integral_constant<int, c>{}),
@@ -1180,11 +1494,15 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
 
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
     // returns hasconverged, leaves needediterations in `its`.
-    auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
+    // (condensed shapes: cmul = the origin's recorded multipliers, requested by the caller -- cached_solve -- which has
+    // also run set_p(target), brought the condensation up to date and formed pf')
+    // (mv, z0m: instances whose potentiometers moved since the origin was taken start from z0m, cached_solve)
+    auto base_solve = [&](double target, bool need, int &its, const double (&cmul)[NRr + 1], bool mv = false, double z0m = 0.0) ACME_LAMBDA -> bool {
         double mul[NN + 2], oj[NPr];
-        if constexpr (S::MULT) LU::template load_stored<S>(mul, ojp);     // requested first: needed last, ~60 instructions on
+        if constexpr (COND) { }
+        else if constexpr (S::MULT) LU::template load_stored<S>(mul, ojp);     // requested first: needed last, ~60 instructions on
         else if constexpr (NN < 7) sfor<0, NP>([&](auto jc) ACME_LAMBDA { oj[decltype(jc)::value] = ojp[decltype(jc)::value * OS]; });   // (likewise; nn = 7: no gain)
-        set_p(target);
+        if constexpr (!COND) set_p(target);
         // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215).  Row r of
         // last_Jp (p - last_p) is  sum_t Jq[r, tc_t] (pfull(p) - pfull(last_p))[tc_t]  (Jp = Jq pexp,
         // src/ACME.jl:246-251): the origin's Jq non-zeros times the change of this row's pfull
@@ -1201,9 +1519,12 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int tt = decltype(tc_)::value;
-                t = fma(otp[S::OS_TV - s0 + tt], pf[tt] - otp[S::OS_PF - s0 + tt], t);
+                t = fma(otp[S::OS_TV - s0 + tt], (COND ? pfr[tt] : pf[tt]) - otp[S::OS_PF - s0 + tt], t);
             });
-            LU::apply_loaded(t, mul);
+            // (condensed: the reduced system's recorded steps; the lanes of the linear rows hold (1, 0, 0) and
+            // A_LL^-1 b_L there, and ride along: z_L of the start comes out of the same replay)
+            if constexpr (COND) LU::template apply_loaded_from<NL, NR>(t, cmul);
+            else LU::apply_loaded(t, mul);
         } else {       // the slab holds J^-1 Jp, row lig
             const double dp = target - lp;
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
@@ -1212,22 +1533,37 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             });
         }
         z = sel(need, lz - t, z);
+        if constexpr (COND) z = sel(need && mv, z0m, z);
         // the loop-carried per-lane flags as integers in vector registers (bit 0 act, 1 conv, 2 accepted):
         // as 64-bit lane masks they were spilled and re-read through v_writelane / v_readlane every pass
         int fl = wv::keepi(need ? 1 : 0);
         its = 0;
         ACME_T(TB_SETUP);
         unsigned long long actm = wv::ballot((fl & 1) != 0);
+        // condensed: the start may lie off the linear rows' subspace if the origin did (bit 3 of fl: this pass is `off`;
+        // bit 4: ... and its iterate was accepted as it stood)
+        if constexpr (COND) fl |= (need && (osub != 0 || mv)) ? 8 : 0;
         do {
             const bool act = (fl & 1) != 0;
             its += fl & 1;
             bool finite, ok, small;
             double dz;
-            linearize(z, act, actm, false, finite, ok, small, dz);
+            if constexpr (COND) {
+                const bool off = (fl & 8) != 0;
+                linearize(z, act, actm, false, finite, ok, small, dz, wv::ballot(off) != 0ull, off);
+            } else {
+                linearize(z, act, actm, false, finite, ok, small, dz);
+            }
             const bool want = act && finite && ok && small;
             const bool stop_bad = act && (!finite || !ok);
             const bool step = act && !stop_bad && !want;
-            z = sel(step, z - dz, z);
+            if constexpr (COND) {
+                z = sel(step, fma(sgn, z, -dz), z);
+                fl = (want && (fl & 8) != 0) ? (fl | 16) : fl;
+                fl &= ~8;
+            } else {
+                z = sel(step, z - dz, z);
+            }
             int nf = fl & ~1;
             // hasconverged is `resmaxabs < tol` even when solve() returned early because J was non-finite
             // or singular (src/solvers.jl:203,219-224); `small` is false for a NaN / inf residual
@@ -1238,6 +1574,14 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             ACME_T(TB_GLUE);
         } while ((actm = wv::ballot((fl & 1) != 0)) != 0ull);
         const bool accepted = (fl & 4) != 0;
+        if constexpr (COND) {
+            // the accepted iterate's z_L: what the linear rows give for its z_N (the lanes' last "residual" is exactly
+            // -(zp_L - W z_N)) -- unless it was accepted off the subspace, as it stood
+            const bool offacc = (fl & 16) != 0;
+            z = sel(accepted && islin && !offacc, -res, z);
+            osub = accepted ? (offacc ? 1 : 0) : osub;
+            opos = accepted ? pf[2] : opos;
+        }
         lz = sel(accepted, z, lz);
         lp = sel(accepted, target, lp);
         return (fl & 6) != 0;
@@ -1294,16 +1638,100 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 const double czl = (valid && caching) ? cz[e * NN + (lig < NN ? lig : 0)] : 0.0;   // HBM, one line
                 lp = hit ? cpl : lp;
                 lz = hit ? czl : lz;
+                if constexpr (COND) osub = hit ? 0 : osub;      // (a stored solution was an accepted iterate: on the subspace)
             }
             reorig = reorig || hit;
         }
-        if (ACME_RARE(wv::ballot(reorig))) {
-            set_p(lp);
-            bool f0, k0, s0;
-            double d0;
-            linearize(reorig ? lz : z, false, 0ull, reorig, f0, k0, s0, d0);
+        bool c;
+        if constexpr (COND) {
+            // Phase 0 (rare): set_extrapolation_origin(solver, lp, lz) for the instances with `reorig`.  Phase 1: the solve
+            // at `target`.  Both start alike -- pfull, the condensation for ITS potentiometer positions, pf' -- hence one
+            // loop with one copy of that code (the phase is wave-uniform and opaque to the optimiser).
+            double cmul[NRr + 1], z0m = 0.0;
+            bool mv = false, mvpre = false, back = false;
+            int ph = wv::opaque(1);
+            for (;;) {
+                if (ph != 0) LU::template load_stored_n<NR, S>(cmul, ojp);       // requested first: needed last
+                if (ph != 0 && back) sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pf[decltype(tc_)::value] = pft[decltype(tc_)::value]; });
+                else set_p(ph != 0 ? target : lp);
+                if (ph != 0 && !back) {
+                    // an origin to (re-)linearise, or potentiometers that moved since the origin was taken (opos is not
+                    // known yet where the origin is stale: settled in phase 0): the origin's turn first
+                    mvpre = inst_any(need && islin && !(pf[2] == opos));
+                    if (ACME_RARE(wv::ballot(reorig || mvpre) != 0ull)) {
+                        sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pft[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
+                        ph = wv::opaque(0);
+                        back = true;
+                        continue;
+                    }
+                }
+                const bool part = ph != 0 ? need : (reorig || mvpre);
+                const bool chg = inst_any(part && islin && !(pf[2] == cpos));
+                if (ACME_RARE(wv::ballot(chg) != 0ull)) condense(chg);
+                prep_reduced();
+                if (ACME_USUAL(ph != 0)) break;
+                // ---- phase 0: pf, pf' and the condensation are the ORIGIN's ----
+                if (wv::ballot(reorig) != 0ull) {
+                    bool f0, k0, s0;
+                    double d0;
+                    const bool roff = reorig && osub != 0;
+                    linearize(reorig ? lz : z, false, 0ull, reorig, f0, k0, s0, d0, wv::ballot(roff) != 0ull, roff);
+                    opos = reorig ? pf[2] : opos;
+                }
+                mv = inst_any(need && islin && !(pft[2] == opos));
+                if (wv::ballot(mv) != 0ull) {
+                    // The potentiometers moved since the origin was taken: z0 = last_z - last_J \ (last_Jp (p - last_p))
+                    // (src/solvers.jl:209-215) on the FULL system, by blocks -- the linear rows' right-hand sides
+                    // t_L = Jq_L dpfull through A_LL^-1 (u_L), the others' corrected by J_NL u_L (through pfull, as
+                    // fq_L u_L), then the origin's recorded reduced elimination with the linear rows riding along.
+                    // Jq at the origin from the FULL q (an `off` evaluation at last_z).
+                    evaluate_c(lz, true, mv);
+                    const wv::pair_t h_ = wv::ld2(&rd.rc[3 * 2 * GROUP]);
+                    const double tvT[3] = {islin ? 1.0 : tv[0], islin ? crw : tv[1], islin ? h_.lo * efl1 : tv[2]};
+                    double dp[3], tt = 0.0;
+                    sfor<0, 3>([&](auto tc_) ACME_LAMBDA {
+                        constexpr int t = decltype(tc_)::value;
+                        dp[t] = pft[t] - pf[t];
+                        tt = fma(tvT[t], dp[t], tt);
+                    });
+                    double uL = 0.0;
+                    wv::fmac_bcast_chain<NL, true>(uL, tt, cd[1]);
+                    const double nu = -uL;
+                    double fql[NT][NLr + 1];
+                    sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                        constexpr int t = decltype(tc_)::value;
+                        sfor<0, (NL + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                            constexpr int j = 2 * decltype(jc)::value;
+                            const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * grow]);
+                            fql[t][j] = v.lo;
+                            fql[t][j + 1] = v.hi;
+                        });
+                    });
+                    double tN = 0.0;
+                    sfor<0, 3>([&](auto tc_) ACME_LAMBDA {
+                        constexpr int t = decltype(tc_)::value;
+                        wv::fmac_bcast_chain<NL, true>(dp[t], nu, fql[t]);
+                        tN = fma(tv[t], dp[t], tN);
+                    });
+                    tt = islin ? uL : tN;
+                    double cm[NRr + 1];
+                    LU::template load_stored_n<NR, S>(cm, ojp);
+                    LU::template apply_loaded_from<NL, NR>(tt, cm);
+                    z0m = lz - tt;
+                }
+                ph = wv::opaque(1);
+            }
+            c = base_solve(target, need, its, cmul, mv, z0m);
+        } else {
+            if (ACME_RARE(wv::ballot(reorig))) {
+                set_p(lp);
+                bool f0, k0, s0;
+                double d0;
+                linearize(reorig ? lz : z, false, 0ull, reorig, f0, k0, s0, d0);
+            }
+            const double nocmul[NRr + 1] = {0.0};
+            c = base_solve(target, need, its, nocmul);
         }
-        const bool c = base_solve(target, need, its);
         if (caching) {
             const bool keep = need && c && its > 5;
             if (ACME_RARE(wv::ballot(keep))) {
@@ -1365,7 +1793,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             if (valid && lig < A.nn_io)     // column-major nn x np per instance; NaN if J is singular there
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
-                    if (j < A.np_io) A.jac_out[(inst * A.np_io + j) * A.nn_io + lig] = mine ? (double)NAN : -jp[j];
+                    if (j < A.np_io) A.jac_out[(inst * A.np_io + j) * A.nn_io + A.zperm[lig]] = mine ? (double)NAN : -jp[j];
                 });
         });
         return;
@@ -1559,7 +1987,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 const bool conv = (hf & 2) != 0;
                 zs[s] = alive ? z : 0.0;
                 if (solve_mode) {   // hand the solver's answer back; no y, no state update
-                    if (valid && lig < A.nn_io) A.z_out[inst * A.nn_io + lig] = z;
+                    if (valid && lig < A.nn_io) A.z_out[inst * A.nn_io + A.zperm[lig]] = z;
                     if (valid && lig == 0) {
                         A.conv_out[inst] = conv ? 1 : 0;
                         A.iters_out[inst] = its_sample;
@@ -1754,6 +2182,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             wv::wave_fence();
         }
         if (lig < RW_WORDS && !solve_mode) A.report[inst * RW_WORDS + lig] = rbuf[lig];
+        if constexpr (COND) if (lig == 0) A.cflags[inst] = osub;
     }
 }
 #undef grow

@@ -110,7 +110,8 @@ constexpr int ACME_NPARTS = 4;
 constexpr int shape_part(int index) {
     constexpr int table[] = {0 /* diode clipper */, 1 /* superover, fixed pots */, 2 /* superover, pots as inputs */,
                              0 /* birdie, fixed vol */, 1 /* birdie, vol as input */, 2 /* linear */, 3 /* generic small */,
-                             3 /* generic medium */, 0 /* generic large */, 2 /* decomposed small */, 1 /* decomposed medium */};
+                             3 /* generic medium */, 0 /* generic large */, 2 /* decomposed small */, 1 /* decomposed medium */,
+                             3 /* superover, pots as inputs, condensed */};
     return index < (int)(sizeof(table) / sizeof(table[0])) ? table[index] : index % ACME_NPARTS;
 }
 bool acme_shape_fns_part0(int index, ShapeFns *out);

@@ -8,7 +8,9 @@
 // descriptor per residual row (= per lane) with every loop-invariant sub-expression of
 // the element functions (src/elements.jl) pre-evaluated in the same operation order.
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -45,11 +47,154 @@ struct Packed {
     std::vector<double> lanec;   // LaneLayout block (models with one nonlinear sub-problem)
     std::vector<int> rowi;
     int nterms = 2, has_bjt = 0, rare_kinds = 0;
+    // condensed shapes (Dims::nl > 0): the kernel's z basis is a permutation of the caller's --
+    // zperm[i] = caller's index of the kernel's z_i, zinv its inverse (identity otherwise) -- and the
+    // lanes' residual rows start with the linear ones (lrows, in pivot order)
+    int zperm[GROUP], zinv[GROUP];
+    std::vector<int> lrows, lcols;
 };
+
+// The condensation plan of a sub-problem: its residual rows that are linear in z for a given p (potentiometer
+// halves, res = v - r w i with w = pos or 1 - pos, src/elements.jl:25-30, whose `pos` entry of q has an all-zero
+// fq row: pos then comes from the inputs / states alone, src/ACME.jl:176-189) and ONE static pivot column of
+// z for each -- chosen by complete pivoting on the row-equilibrated A_L = fq[v] - r w fq[i] at mid travel and
+// accepted only if A_LL = A_L[:, lcols] stays well conditioned over the whole travel of every pot
+// (equilibrated condition number <= 1e8 on a 3-point grid per pot, both end stops pulled in by 2 %: a pot AT an
+// end stop can short a branch and make the model itself singular, e.g. the drive pot of examples/superover.jl
+// at 1.0).  With the rows in lanes 0 .. nl-1 and the columns first, the kernel eliminates them once per change
+// of the pot positions instead of once per Newton iteration (acme_kernel.h: "condensed solve").
+struct CondPlan {
+    std::vector<int> lrows, lcols;      // residual rows / z columns, in pivot order
+};
+inline bool plan_condense(const HostSub &s, CondPlan &plan) {
+    struct LinRow { int row, v, i; double r, w0, w1; int pot; };
+    std::vector<LinRow> rows;
+    int npots = 0;
+    for (size_t e = 0; e < s.kind.size(); ++e) {
+        if (s.kind[e] != EK_POT) continue;
+        const int q0 = s.qoff[e];
+        bool pos_free = true;
+        for (int j = 0; j < s.nn; ++j)
+            if (s.fq[(size_t)j * s.nq + q0 + 4] != 0.0) pos_free = false;
+        if (!pos_free) continue;
+        const double r = s.par[e * MAX_ELEM_PAR];
+        rows.push_back({s.roff[e] + 0, q0 + 0, q0 + 2, r, 0.0, 1.0, npots});
+        rows.push_back({s.roff[e] + 1, q0 + 1, q0 + 3, r, 1.0, -1.0, npots});
+        ++npots;
+    }
+    const int nl = (int)rows.size(), nn = s.nn;
+    plan.lrows.clear();
+    plan.lcols.clear();
+    if (nl == 0 || nl >= nn || npots > 8) return false;
+    auto build = [&](const std::vector<double> &pos, std::vector<double> &A) {     // nl x nn, row-major, equilibrated rows
+        A.assign((size_t)nl * nn, 0.0);
+        for (int k = 0; k < nl; ++k) {
+            const LinRow &R = rows[k];
+            const double rw = R.r * (R.w0 + R.w1 * pos[R.pot]);
+            double mx = 0.0;
+            for (int j = 0; j < nn; ++j) {
+                A[(size_t)k * nn + j] = s.fq[(size_t)j * s.nq + R.v] - rw * s.fq[(size_t)j * s.nq + R.i];
+                mx = std::fmax(mx, std::fabs(A[(size_t)k * nn + j]));
+            }
+            if (mx > 0.0) for (int j = 0; j < nn; ++j) A[(size_t)k * nn + j] /= mx;
+        }
+    };
+    std::vector<double> A, pos(npots, 0.5);
+    build(pos, A);
+    std::vector<int> rleft(nl), cleft(nn);
+    for (int k = 0; k < nl; ++k) rleft[k] = k;
+    for (int j = 0; j < nn; ++j) cleft[j] = j;
+    std::vector<int> prow, pcol;
+    for (int step = 0; step < nl; ++step) {
+        double best = 0.0;
+        int br = -1, bc = -1;
+        for (int r : rleft)
+            for (int c : cleft)
+                if (std::fabs(A[(size_t)r * nn + c]) > best) { best = std::fabs(A[(size_t)r * nn + c]); br = r; bc = c; }
+        if (br < 0 || best < 1e-12) return false;       // the linear rows are dependent at mid travel
+        prow.push_back(br);
+        pcol.push_back(bc);
+        rleft.erase(std::find(rleft.begin(), rleft.end(), br));
+        cleft.erase(std::find(cleft.begin(), cleft.end(), bc));
+        for (int r : rleft) {
+            const double l = A[(size_t)r * nn + bc] / A[(size_t)br * nn + bc];
+            for (int c = 0; c < nn; ++c) A[(size_t)r * nn + c] -= l * A[(size_t)br * nn + c];
+        }
+    }
+    // conditioning of A_LL over the pots' travel
+    const double grid[3] = {0.02, 0.5, 0.98};
+    long combos = 1;
+    for (int k = 0; k < npots; ++k) combos *= 3;
+    for (long c = 0; c < combos; ++c) {
+        long cc = c;
+        for (int k = 0; k < npots; ++k) { pos[k] = grid[cc % 3]; cc /= 3; }
+        build(pos, A);
+        std::vector<double> B((size_t)nl * nl), Binv((size_t)nl * nl, 0.0);
+        for (int i = 0; i < nl; ++i) {
+            double mx = 0.0;
+            for (int j = 0; j < nl; ++j) mx = std::fmax(mx, std::fabs(A[(size_t)prow[i] * nn + pcol[j]]));
+            if (mx == 0.0) return false;
+            for (int j = 0; j < nl; ++j) B[(size_t)i * nl + j] = A[(size_t)prow[i] * nn + pcol[j]] / mx;
+            Binv[(size_t)i * nl + i] = 1.0;
+        }
+        double nB = 0.0;
+        for (int i = 0; i < nl; ++i) {
+            double rs = 0.0;
+            for (int j = 0; j < nl; ++j) rs += std::fabs(B[(size_t)i * nl + j]);
+            nB = std::fmax(nB, rs);
+        }
+        for (int k = 0; k < nl; ++k) {       // Gauss-Jordan with partial pivoting on [B | I]
+            int pr = k;
+            for (int i = k + 1; i < nl; ++i)
+                if (std::fabs(B[(size_t)i * nl + k]) > std::fabs(B[(size_t)pr * nl + k])) pr = i;
+            if (B[(size_t)pr * nl + k] == 0.0) return false;
+            if (pr != k)
+                for (int j = 0; j < nl; ++j) {
+                    std::swap(B[(size_t)k * nl + j], B[(size_t)pr * nl + j]);
+                    std::swap(Binv[(size_t)k * nl + j], Binv[(size_t)pr * nl + j]);
+                }
+            const double inv = 1.0 / B[(size_t)k * nl + k];
+            for (int j = 0; j < nl; ++j) { B[(size_t)k * nl + j] *= inv; Binv[(size_t)k * nl + j] *= inv; }
+            for (int i = 0; i < nl; ++i) {
+                if (i == k) continue;
+                const double l = B[(size_t)i * nl + k];
+                for (int j = 0; j < nl; ++j) {
+                    B[(size_t)i * nl + j] -= l * B[(size_t)k * nl + j];
+                    Binv[(size_t)i * nl + j] -= l * Binv[(size_t)k * nl + j];
+                }
+            }
+        }
+        double nI = 0.0;
+        for (int i = 0; i < nl; ++i) {
+            double rs = 0.0;
+            for (int j = 0; j < nl; ++j) rs += std::fabs(Binv[(size_t)i * nl + j]);
+            nI = std::fmax(nI, rs);
+        }
+        if (!(nB * nI <= 1e8)) return false;
+    }
+    for (int k = 0; k < nl; ++k) {
+        plan.lrows.push_back(rows[prow[k]].row);
+        plan.lcols.push_back(pcol[k]);
+    }
+    return true;
+}
+// the model with the z basis of its (single) sub-problem permuted: kernel column i = caller's column zperm[i]
+inline void permute_z(HostModel &m, const int *zperm) {
+    HostSub &s = m.subs[0];
+    const int nn = s.nn;
+    std::vector<double> fq(s.fq.size()), iz(nn), c(m.c.size()), fy(m.fy.size());
+    for (int j = 0; j < nn; ++j) {
+        for (int i = 0; i < s.nq; ++i) fq[(size_t)j * s.nq + i] = s.fq[(size_t)zperm[j] * s.nq + i];
+        iz[j] = s.init_z[zperm[j]];
+        for (int i = 0; i < m.nx; ++i) c[(size_t)j * m.nx + i] = m.c[(size_t)zperm[j] * m.nx + i];
+        for (int i = 0; i < m.ny; ++i) fy[(size_t)j * m.ny + i] = m.fy[(size_t)zperm[j] * m.ny + i];
+    }
+    s.fq = fq; s.init_z = iz; m.c = c; m.fy = fy;
+}
 
 inline const std::vector<Dims> &shape_list() {
     static const std::vector<Dims> v = {
-#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub) Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0},
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub, nl) Dims{nn, nq, np, nx, nu, ny, rare, (nn) > 0 ? (nsub) : 0, nl},
         ACME_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -81,10 +226,11 @@ inline bool choose_shape(const Dims &d, Dims &out) {
             if (d.nsub > s.nsub) continue;
             if (pass == 0 && s.nn != 0) continue;
             if (s.nn == d.nn && s.nq == d.nq && s.np == d.np && s.nx == d.nx && s.nu == d.nu && s.ny == d.ny &&
-                s.nsub == d.nsub) {
+                s.nsub == d.nsub && s.nl == d.nl) {
                 out = s;
                 return true;
             }
+            if (s.nl != 0) continue;     // a condensed kernel is built for exactly its model
             bool fits = d.nn <= s.nn && d.np <= s.np && d.nx <= s.nx && d.nu <= s.nu && d.ny <= s.ny &&
                         d.nq + (s.nn - d.nn) <= s.nq;
             if (!fits) continue;
@@ -223,8 +369,65 @@ inline bool describe_element(int kind, const double *p, int er, int q0_, double 
     return true;
 }
 
-inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Dims *force_shape = nullptr) {
+inline bool pack_model(const HostModel &m_in, Packed &P, std::string &err, const Dims *force_shape = nullptr,
+                       const Packed *force_plan = nullptr) {
+    // Condensation (see CondPlan): decided here, once per model -- per-instance models of a batch take the batch
+    // model's plan (force_plan) so that they share its element table and lane assignment.  ACME_CONDENSE=0 in the
+    // environment keeps the plain kernel (A/B measurements, tests of the uncondensed path).
+    for (int i = 0; i < GROUP; ++i) P.zperm[i] = P.zinv[i] = i;
+    P.lrows.clear();
+    P.lcols.clear();
+    HostModel m_perm;
+    const HostModel *mp = &m_in;
+    int nl_model = 0;
+    {
+        const char *e = getenv("ACME_CONDENSE");
+        const bool allowed = !(e && e[0] == '0') && m_in.subs.size() == 1 && (!force_shape || force_shape->nl > 0);
+        CondPlan plan;
+        bool have = false;
+        if (allowed && force_plan && !force_plan->lrows.empty()) {
+            plan.lrows = force_plan->lrows;
+            plan.lcols = force_plan->lcols;
+            have = true;
+        } else if (allowed && !force_plan) {
+            have = plan_condense(m_in.subs[0], plan);
+        }
+        if (have) {     // is there a kernel built for it?
+            const HostSub &s0 = m_in.subs[0];
+            Dims probe{s0.nn, s0.nq, s0.np, m_in.nx, m_in.nu, m_in.ny, 0, 1, (int)plan.lrows.size()};
+            bool found = false;
+            for (const Dims &sh : shape_list())
+                if (sh.nn == probe.nn && sh.nq == probe.nq && sh.np == probe.np && sh.nx == probe.nx && sh.nu == probe.nu &&
+                    sh.ny == probe.ny && sh.nsub == 1 && sh.nl == probe.nl && !sh.rare)
+                    found = true;
+            if (force_shape && force_shape->nl != probe.nl) found = false;
+            if (found) {
+                nl_model = probe.nl;
+                P.lrows = plan.lrows;
+                P.lcols = plan.lcols;
+                std::vector<char> used(s0.nn, 0);
+                int k = 0;
+                for (int c : plan.lcols) { P.zperm[k++] = c; used[c] = 1; }
+                for (int c = 0; c < s0.nn; ++c) if (!used[c]) P.zperm[k++] = c;
+                for (int i = 0; i < s0.nn; ++i) P.zinv[P.zperm[i]] = i;
+                m_perm = m_in;
+                permute_z(m_perm, P.zperm);
+                // lanes: the linear rows first (pivot order), then the others in the order of the caller's hint
+                std::vector<int> order = plan.lrows, rest = s0.row_order;
+                if (rest.empty()) for (int r = 0; r < s0.nn; ++r) rest.push_back(r);
+                for (int r : rest) if (std::find(plan.lrows.begin(), plan.lrows.end(), r) == plan.lrows.end()) order.push_back(r);
+                m_perm.subs[0].row_order = order;
+                mp = &m_perm;
+            }
+        }
+    }
+    if (force_shape && force_shape->nl != nl_model) {
+        err = "model cannot be condensed like the batch's model (its potentiometer rows differ)";
+        return false;
+    }
+    const HostModel &m = *mp;
     Dims d{};
+    d.nl = nl_model;
     d.nx = m.nx; d.nu = m.nu; d.ny = m.ny;
     d.nsub = (int)m.subs.size();
     if (d.nsub > MAX_NSUB) {
@@ -260,7 +463,7 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
     Dims S{};
     auto fits = [&](const Dims &s_) {
         return d.nn <= s_.nn && d.np <= s_.np && d.nx <= s_.nx && d.nu <= s_.nu && d.ny <= s_.ny && d.nsub <= s_.nsub &&
-               d.nq + (s_.nn - d.nn) <= s_.nq && (!d.rare || s_.rare);
+               d.nq + (s_.nn - d.nn) <= s_.nq && (!d.rare || s_.rare) && s_.nl == d.nl;
     };
     if (force_shape) {
         S = *force_shape;
@@ -354,6 +557,9 @@ inline bool pack_model(const HostModel &m, Packed &P, std::string &err, const Di
             rowc[(size_t)UR_G0 * GROUP + r] = 1.0;
             for (int t = 0; t < 4; ++t) rowi[(3 + t) * GROUP + r] = qrow;
         }
+        // condensed shapes: row 15 (never a residual row, static_assert in Shape) holds the constants the lanes of
+        // the LINEAR rows evaluate in the Newton loop -- res = e0, Jq = (1, 0, 0): see acme_kernel.h
+        if (S.nl > 0) rowc[(size_t)UR_G0 * GROUP + (GROUP - 1)] = 1.0;
         // row-gathered copies of fq / pexp / q0 (see Layout): slot `pos` = the lane position of
         // the residual row, term t = its t-th Jq non-zero
         for (int pos = 0; pos < S.nn; ++pos)

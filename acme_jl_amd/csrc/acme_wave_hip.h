@@ -113,6 +113,12 @@ template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(d
         fmac_bcast_seg<13, N - 13, false, OFF>(acc, src, mul);
     }
 }
+// ... with the broadcast lanes L0 .. L0 + N - 1 and the multipliers mul[MB .. MB + N - 1] chosen independently (the
+// condensed shapes multiply the reduced unknowns, lanes NL .. NN-1, with a register block indexed from 0)
+template <int L0, int N, bool WAIT, int MB = 0, int M> ACME_DEV void fmac_bcast_chain_from(double &acc, double src, const double (&mul)[M]) {
+    static_assert(N >= 0 && N <= 13 && L0 >= 0 && L0 + N <= 16 && MB >= 0 && MB + N <= M, "one DPP row, one statement");
+    if constexpr (N > 0) fmac_bcast_seg<L0, N, WAIT, MB - L0>(acc, src, mul);
+}
 #undef ACME_FB_CASE
 // The replay of a recorded elimination,  acc += (lane k of acc's row) * mul[k]  for k = 0 .. N-1,  as ONE
 // statement: every step reads through DPP what the step before wrote, so each carries its two wait states
@@ -148,6 +154,17 @@ template <int N, int M> ACME_DEV void fmac_self_chain(double &acc, const double 
         fmac_self_seg<13, N - 13>(acc, mul);
     }
 }
+// ... replaying the steps of lanes L0 .. L0 + N - 1 with the multipliers mul[0 .. N - 1]
+#define ACME_FS_CASE_FROM(n) \
+    if constexpr (CNT == n) asm volatile(ACME_FSS_##n : [acc] "+v"(acc) : ACME_FBI_##n);
+template <int L0, int N, int M> ACME_DEV void fmac_self_chain_from(double &acc, const double (&mul)[M]) {
+    static_assert(N >= 1 && N <= 13 && L0 >= 0 && L0 + N <= 16 && M >= N, "one DPP row, one statement");
+    constexpr int K0 = L0, CNT = N, OFF = -L0;
+    ACME_FS_CASE_FROM(1) ACME_FS_CASE_FROM(2) ACME_FS_CASE_FROM(3) ACME_FS_CASE_FROM(4) ACME_FS_CASE_FROM(5) ACME_FS_CASE_FROM(6)
+    ACME_FS_CASE_FROM(7) ACME_FS_CASE_FROM(8) ACME_FS_CASE_FROM(9) ACME_FS_CASE_FROM(10) ACME_FS_CASE_FROM(11)
+    ACME_FS_CASE_FROM(12) ACME_FS_CASE_FROM(13)
+}
+#undef ACME_FS_CASE_FROM
 #undef ACME_FS_CASE
 
 // two wait states before a run of fmac_bcast statements whose source may have just been produced

@@ -173,7 +173,7 @@ template <class S, bool LOW> static KernelFns make_fns() {
     return f;
 }
 template <class S> static KernelEntry make_entry() {
-    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB},
+    return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB, S::NL},
                        make_fns<S, false>(), make_fns<S, true>(), nullptr,
                        S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
                        lane_lds<S>(false), lane_lds<S>(true), &launch_any<S, 2>};
@@ -181,7 +181,7 @@ template <class S> static KernelEntry make_entry() {
 
 static const std::vector<KernelEntry> &kernel_table() {
     static const std::vector<KernelEntry> t = {
-#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub) make_entry<Shape<nn, nq, np, nx, nu, ny, rare, nsub>>(),
+#define ACME_X(nn, nq, np, nx, nu, ny, rare, nsub, nl) make_entry<Shape<nn, nq, np, nx, nu, ny, rare, nsub, nl>>(),
         ACME_EMU_SHAPES(ACME_X)
 #undef ACME_X
     };
@@ -190,7 +190,7 @@ static const std::vector<KernelEntry> &kernel_table() {
 
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
-        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub)
+        if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub && k.d.nl == d.nl)
             return &k;
     return nullptr;
 }

@@ -183,6 +183,14 @@ template <int I, int N, int OFF, int M> ACME_DEV void fmac_bcast_chain_(double &
     if constexpr (I < N) { fmac_bcast<I>(acc, src, mul[OFF + I]); fmac_bcast_chain_<I + 1, N, OFF, M>(acc, src, mul); }
 }
 template <int N, bool WAIT, int OFF = 0, int M> ACME_DEV void fmac_bcast_chain(double &acc, double src, const double (&mul)[M]) { fmac_bcast_chain_<0, N, OFF, M>(acc, src, mul); }
+template <int I, int L0, int N, int MB, int M> ACME_DEV void fmac_bcast_chain_from_(double &acc, double src, const double (&mul)[M]) {
+    if constexpr (I < N) { fmac_bcast<L0 + I>(acc, src, mul[MB + I]); fmac_bcast_chain_from_<I + 1, L0, N, MB, M>(acc, src, mul); }
+}
+template <int L0, int N, bool WAIT, int MB = 0, int M> ACME_DEV void fmac_bcast_chain_from(double &acc, double src, const double (&mul)[M]) { fmac_bcast_chain_from_<0, L0, N, MB, M>(acc, src, mul); }
+template <int I, int L0, int N, int M> ACME_DEV void fmac_self_chain_from_(double &acc, const double (&mul)[M]) {
+    if constexpr (I < N) { fmac_bcast_self<L0 + I, true>(acc, mul[I]); fmac_self_chain_from_<I + 1, L0, N, M>(acc, mul); }
+}
+template <int L0, int N, int M> ACME_DEV void fmac_self_chain_from(double &acc, const double (&mul)[M]) { fmac_self_chain_from_<0, L0, N, M>(acc, mul); }
 ACME_DEV void dpp_wait() {}
 ACME_DEV bool lanes(unsigned long long mask);
 ACME_DEV double recip(double d);
