@@ -139,7 +139,10 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
     // them since their row constants went to LDS): no scalar loads per evaluate!, and 32 of the 102 scalar
     // registers back -- headline +1.5 %, config 4 +2.0 % (with 8 spilled registers), birdie +3.3 %
-    static constexpr bool EXPV = !RARE;
+#ifndef ACME_COND_SCALAR_EXP
+#define ACME_COND_SCALAR_EXP 0
+#endif
+    static constexpr bool EXPV = !RARE && !(NL_ > 0 && ACME_COND_SCALAR_EXP);
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
     static constexpr int OS_MUL = 0, OS_DINV = NE, OS_TV = NE + 1, OS_PF = NE + 1 + NT;
     static constexpr int OSLOTS = MULT ? (NE + 1 + 2 * NT + 1) & ~1 : NP;
@@ -1328,7 +1331,8 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 sfor<0, NT>([&](auto tc_) ACME_LAMBDA { eu[decltype(tc_)::value] = (off && !islin) ? ef[decltype(tc_)::value] : e[decltype(tc_)::value]; });
             }
             double exA, exB;
-            exp_junction2(eu[0] * urc[0], eu[1] * urc[1], exA, exB, etv);
+            if constexpr (S::EXPV) exp_junction2(eu[0] * urc[0], eu[1] * urc[1], exA, exB, etv);
+            else exp_junction2(eu[0] * urc[0], eu[1] * urc[1], exA, exB, wv::load_exp_tab());
             eval_row_unified_c<NT>(urc, eu, exA, exB, res, tv);
             sfor<0, NR>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
