@@ -1203,7 +1203,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     int osub = 1;                                  // the origin (lp, lz) may lie off the subspace (KArgs::cflags)
     if constexpr (COND) osub = valid ? (A.cflags[inst] & 1) : 0;
     double opos = (double)NAN;                     // lanes < NL: the potentiometer position at the origin (lp, lz)
-    double rhs = 0.0, lres = 0.0, efl1 = 0.0;
+    double corr = 0.0, lres = 0.0, efl1 = 0.0;
     auto inst_any = [&](bool x) ACME_LAMBDA -> bool { return ((wv::ballot(x) >> (grp * GROUP)) & 0xFFFFull) != 0ull; };
     // the rows' fq entries (two columns per LDS read), as in evaluate
     auto load_fq_rows = [&](double (&fqv)[NT][NNr + 1]) ACME_LAMBDA {
@@ -1313,42 +1313,99 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 urc[2 * p] = v.lo;
                 urc[2 * p + 1] = v.hi;
             });
-            double e[NT], ef[NT], eu[NT];
+            double e[NT], de[NT];       // de: full q minus reduced q' (off only)
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pfr[decltype(tc_)::value]; });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
                 wv::fmac_bcast_chain_from<NL, NR, t == 0>(e[t], zz, cd[t]);
             });
-            sfor<0, NT>([&](auto tc_) ACME_LAMBDA { ef[decltype(tc_)::value] = eu[decltype(tc_)::value] = e[decltype(tc_)::value]; });
             if (ACME_RARE(offany)) {
-                double fqv[NT][NNr + 1];
+                double fqv[NT][NNr + 1], ef[NT];
                 load_fq_rows(fqv);
                 sfor<0, NT>([&](auto tc_) ACME_LAMBDA { ef[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
                 sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                     constexpr int t = decltype(tc_)::value;
                     wv::fmac_bcast_chain<NN, true>(ef[t], zz, fqv[t]);
                 });
-                sfor<0, NT>([&](auto tc_) ACME_LAMBDA { eu[decltype(tc_)::value] = (off && !islin) ? ef[decltype(tc_)::value] : e[decltype(tc_)::value]; });
+                lres = fma(crw, ef[1], ef[0]);
+                efl1 = ef[1];
+                sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                    constexpr int t = decltype(tc_)::value;
+                    de[t] = ef[t] - e[t];
+                    e[t] = (off && !islin) ? ef[t] : e[t];
+                });
             }
             double exA, exB;
-            if constexpr (S::EXPV) exp_junction2(eu[0] * urc[0], eu[1] * urc[1], exA, exB, etv);
-            else exp_junction2(eu[0] * urc[0], eu[1] * urc[1], exA, exB, wv::load_exp_tab());
-            eval_row_unified_c<NT>(urc, eu, exA, exB, res, tv);
+            if constexpr (S::EXPV) exp_junction2(e[0] * urc[0], e[1] * urc[1], exA, exB, etv);
+            else exp_junction2(e[0] * urc[0], e[1] * urc[1], exA, exB, wv::load_exp_tab());
+            eval_row_unified_c<NT>(urc, e, exA, exB, res, tv);
             sfor<0, NR>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;
                 double acc = tv[0] * cd[0][j];
                 sfor<1, NT>([&](auto tc_) ACME_LAMBDA { acc = fma(tv[decltype(tc_)::value], cd[decltype(tc_)::value][j], acc); });
                 a[NL + j] = acc;
             });
-            rhs = res;
             if (ACME_RARE(offany)) {
-                double corr = 0.0;
-                sfor<0, NT>([&](auto tc_) ACME_LAMBDA { corr = fma(tv[decltype(tc_)::value], ef[decltype(tc_)::value] - e[decltype(tc_)::value], corr); });
-                rhs = (off && !islin) ? res - corr : res;
-                lres = fma(crw, ef[1], ef[0]);
-                efl1 = ef[1];
+                double c_ = 0.0;
+                sfor<0, NT>([&](auto tc_) ACME_LAMBDA { c_ = fma(tv[decltype(tc_)::value], de[decltype(tc_)::value], c_); });
+                corr = (off && !islin) ? c_ : 0.0;
             }
         }
+    };
+
+    // One pass of the condensed Newton iteration: evaluate_c, then the NR steps of the elimination with the residual
+    // riding along (dz); for an iterate whose residual is below tol (or `force`) the lanes record the steps, the row's
+    // Jq non-zeros and its pf' entries in the origin slab, as linearize does.  Returns `mine`: this instance's pivots
+    // failed the threshold, or the result is not finite -- the caller leaves the Newton loop, lets the lanes re-learn
+    // their order (relearn_c) and repeats the pass.  Nothing in here assigns what the Newton loop only reads (cd, pf',
+    // the lanes' rows): kept inside the loop, the re-learning made them loop-carried values with one register copy
+    // each -- 30 of them -- per iteration.
+    auto lin_c = [&](double zz, bool act, unsigned long long actm, bool force, bool &small, double &dz, bool offany, bool off) ACME_LAMBDA -> bool {
+        bool mine = false;
+        if constexpr (COND) {
+            evaluate_c(zz, offany, off);
+            unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4(((1ull << NN) - 1ull) & ~((1ull << NL) - 1ull));
+            if (ACME_RARE(offany)) big |= wv::ballot(off && islin && !(fabs(lres) < tol_v));     // (off the subspace, the linear rows count)
+            small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
+            const bool want = force || (act && small);
+            dz = res;
+            if (ACME_RARE(offany)) dz = res - corr;
+            double none[1] = {0.0}, dinv = 0.0;
+            const bool recording = wv::ballot(want) != 0ull;
+            unsigned long long viol = LU::template solve_range<NL, NN, 0, true, S>(a, dz, none, ojp, want && lig < NN, dinv);
+            viol &= actm | wv::ballot(force);
+            mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
+            if (recording) {
+                if (want && !mine && lig < NN)
+                    sfor<(NR + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
+                        constexpr int c = 2 * decltype(cc)::value;
+                        auto slotv = [&](auto sc) ACME_LAMBDA -> double {
+                            constexpr int sl = decltype(sc)::value;
+                            if constexpr (sl < S::OS_TV + NT) return tv[sl - S::OS_TV];
+                            else if constexpr (sl < S::OS_PF + NT) return pfr[sl - S::OS_PF];
+                            else return 0.0;
+                        };
+                        wv::st2(&ojp[S::oslot(c)], slotv(std::integral_constant<int, c>{}), slotv(std::integral_constant<int, c + 1>{}));
+                    });
+                stale = want ? (mine ? 1 : 0) : stale;
+            }
+        }
+        return mine;
+    };
+    // the instances with `who` re-learn the order of their reduced system's rows: the reference's partially pivoted LU
+    // (src/solvers.jl:58-78) on S at zz, just to find the pivot order, which the lanes adopt.  false: S is singular.
+    auto relearn_c = [&](double zz, bool who, bool offany, bool off) ACME_LAMBDA -> bool {
+        bool okp = true;
+        if constexpr (COND) {
+            evaluate_c(zz, offany, off);
+            int orig;
+            okp = LU::template pivot_order_range<NL, NN>(a, orig, lig, grp);
+            orig = who ? orig : lig;
+            adopt(orig);
+            stale = who ? 1 : stale;
+            okp = who ? okp : true;
+        }
+        return okp;
     };
 
     // One Newton linearisation at z: evaluate! (res, J), then solve J dz = res by in-place
@@ -1368,9 +1425,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // instance changed its row order without storing a new origin, or a recorded elimination was
     // discarded -- and has to be rebuilt before the next extrapolation (cached_solve does).
     // (actm: the caller's ballot of `act` -- it has it anyway, as its loop condition)
-    // (condensed shapes: offany / off -- this iterate may lie off the linear rows' subspace, see evaluate_c)
-    auto linearize = [&](double zz, bool act, unsigned long long actm, bool force, bool &finite, bool &ok, bool &small, double &dz,
-                         bool offany = false, bool off = false) ACME_LAMBDA {
+    auto linearize = [&](double zz, bool act, unsigned long long actm, bool force, bool &finite, bool &ok, bool &small, double &dz) ACME_LAMBDA {
         int okf = 1;     // `ok`: carried as an integer in a vector register
         bool want, recording, mine;
         double jp[NPr];
@@ -1380,18 +1435,14 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         auto eliminate = [&]() ACME_LAMBDA -> unsigned long long {
             // only the boolean is needed, so no max-reduction -- one compare and a ballot; a NaN
             // residual counts as not small
-            unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4(((1ull << NN) - 1ull) & ~((1ull << (COND ? NL : 0)) - 1ull));
-            if constexpr (COND)         // (the linear rows count where the iterate may be off their subspace)
-                if (ACME_RARE(offany)) big |= wv::ballot(off && islin && !(fabs(lres) < tol_v));
+            const unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4((1ull << NN) - 1ull);
             small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
             want = force || (act && finite && small);
             unsigned long long viol;
             double none[1] = {0.0};
-            dz = COND ? rhs : res;
+            dz = res;
             recording = wv::ballot(want) != 0ull;
-            if constexpr (COND) {
-                viol = LU::template solve_range<NL, NN, 0, true, S>(a, dz, none, ojp, want && lig < NN, dinv);
-            } else if constexpr (S::MULT) {
+            if constexpr (S::MULT) {
                 // ONE elimination for iterates that become the origin and for those that do not: the recording
                 // costs no arithmetic (the multipliers exist anyway), only the predicated stores at its end
                 viol = LU::template solve_inplace<0, true, S, S::GJHEAD, S::SAFE0>(a, dz, none, ojp, S::LITROWS ? and_rows<(1ull << NN) - 1ull, true>(want) : (want && lig < NN), dinv);
@@ -1413,27 +1464,22 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             return viol;
         };
         // The usual pass, as straight-line code (no phase variable, no loop head to copy registers at) ...
-        if constexpr (COND) { evaluate_c(zz, offany, off); finite = true; }
-        else finite = evaluate(zz);
+        finite = evaluate(zz);
         ACME_T(TB_EVAL);
         if (ACME_RARE(eliminate() != 0ull)) {
             // ... and the rare one: some instance of the wave has to re-learn its pivot order.  Only the
             // instances that tripped the threshold change their row order: what an instance computes must
             // not depend on which other instances share its wave.
             const bool relearn = mine;
-            if constexpr (COND) evaluate_c(zz, offany, off);
-            else (void)evaluate(zz);                  // J once more (the elimination has consumed it)
+            (void)evaluate(zz);                  // J once more (the elimination has consumed it)
             int orig;
-            bool okp;
-            if constexpr (COND) okp = LU::template pivot_order_range<NL, NN>(a, orig, lig, grp);     // (the reduced system's rows only)
-            else okp = LU::pivot_order(a, orig, lig, grp);
+            const bool okp = LU::pivot_order(a, orig, lig, grp);
             okf = relearn ? (okp ? 1 : 0) : 1;
             orig = relearn ? orig : lig;
             adopt(orig);
             if constexpr (S::MULT) stale = relearn ? 1 : stale;   // the recorded elimination is per row order
             ACME_T(TB_PIVOT);
-            if constexpr (COND) evaluate_c(zz, offany, off);
-            else finite = evaluate(zz);               // ... in the new row order
+            finite = evaluate(zz);               // ... in the new row order
             (void)eliminate();
         }
         okf = mine ? 0 : okf;
@@ -1442,13 +1488,13 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 if constexpr (S::MULT) {
                     // the rest of the entry -- the row's Jq non-zeros and pfull entries -- as 16-byte pairs
                     // too (the multipliers and 1/pivot went in at the end of the elimination)
-                    sfor<(S::NE + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
+                    sfor<(NN + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
                         constexpr int c = 2 * decltype(cc)::value;
                         auto slotv = [&](auto sc) ACME_LAMBDA -> double {
                             constexpr int sl = decltype(sc)::value;
-                            if constexpr (sl == S::OS_DINV) return dinv;
+                            if constexpr (sl == NN) return dinv;
                             else if constexpr (sl < S::OS_TV + NT) return tv[sl - S::OS_TV];
-                            else if constexpr (sl < S::OS_PF + NT) return COND ? pfr[sl - S::OS_PF] : pf[sl - S::OS_PF];
+                            else if constexpr (sl < S::OS_PF + NT) return pf[sl - S::OS_PF];
                             else return 0.0;
                         };
                         wv::st2(&ojp[S::oslot(c)], slotv(std::integral_constant<int, c>{}),
@@ -1498,15 +1544,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
 
     // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`;
     // returns hasconverged, leaves needediterations in `its`.
-    // (condensed shapes: cmul = the origin's recorded multipliers, requested by the caller -- cached_solve -- which has
-    // also run set_p(target), brought the condensation up to date and formed pf')
-    // (mv, z0m: instances whose potentiometers moved since the origin was taken start from z0m, cached_solve)
-    auto base_solve = [&](double target, bool need, int &its, const double (&cmul)[NRr + 1], bool mv = false, double z0m = 0.0) ACME_LAMBDA -> bool {
+    auto base_solve = [&](double target, bool need, int &its) ACME_LAMBDA -> bool {
         double mul[NN + 2], oj[NPr];
-        if constexpr (COND) { }
-        else if constexpr (S::MULT) LU::template load_stored<S>(mul, ojp);     // requested first: needed last, ~60 instructions on
+        if constexpr (S::MULT) LU::template load_stored<S>(mul, ojp);     // requested first: needed last, ~60 instructions on
         else if constexpr (NN < 7) sfor<0, NP>([&](auto jc) ACME_LAMBDA { oj[decltype(jc)::value] = ojp[decltype(jc)::value * OS]; });   // (likewise; nn = 7: no gain)
-        if constexpr (!COND) set_p(target);
+        set_p(target);
         // z <- last_z - last_J \\ (last_Jp * (p - last_p))  (src/solvers.jl:209-215).  Row r of
         // last_Jp (p - last_p) is  sum_t Jq[r, tc_t] (pfull(p) - pfull(last_p))[tc_t]  (Jp = Jq pexp,
         // src/ACME.jl:246-251): the origin's Jq non-zeros times the change of this row's pfull
@@ -1523,12 +1565,9 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 constexpr int tt = decltype(tc_)::value;
-                t = fma(otp[S::OS_TV - s0 + tt], (COND ? pfr[tt] : pf[tt]) - otp[S::OS_PF - s0 + tt], t);
+                t = fma(otp[S::OS_TV - s0 + tt], pf[tt] - otp[S::OS_PF - s0 + tt], t);
             });
-            // (condensed: the reduced system's recorded steps; the lanes of the linear rows hold (1, 0, 0) and
-            // A_LL^-1 b_L there, and ride along: z_L of the start comes out of the same replay)
-            if constexpr (COND) LU::template apply_loaded_from<NL, NR>(t, cmul);
-            else LU::apply_loaded(t, mul);
+            LU::apply_loaded(t, mul);
         } else {       // the slab holds J^-1 Jp, row lig
             const double dp = target - lp;
             sfor<0, NP>([&](auto jc) ACME_LAMBDA {
@@ -1537,37 +1576,22 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             });
         }
         z = sel(need, lz - t, z);
-        if constexpr (COND) z = sel(need && mv, z0m, z);
         // the loop-carried per-lane flags as integers in vector registers (bit 0 act, 1 conv, 2 accepted):
         // as 64-bit lane masks they were spilled and re-read through v_writelane / v_readlane every pass
         int fl = wv::keepi(need ? 1 : 0);
         its = 0;
         ACME_T(TB_SETUP);
         unsigned long long actm = wv::ballot((fl & 1) != 0);
-        // condensed: the start may lie off the linear rows' subspace if the origin did (bit 3 of fl: this pass is `off`;
-        // bit 4: ... and its iterate was accepted as it stood)
-        if constexpr (COND) fl |= (need && (osub != 0 || mv)) ? 8 : 0;
         do {
             const bool act = (fl & 1) != 0;
             its += fl & 1;
             bool finite, ok, small;
             double dz;
-            if constexpr (COND) {
-                const bool off = (fl & 8) != 0;
-                linearize(z, act, actm, false, finite, ok, small, dz, wv::ballot(off) != 0ull, off);
-            } else {
-                linearize(z, act, actm, false, finite, ok, small, dz);
-            }
+            linearize(z, act, actm, false, finite, ok, small, dz);
             const bool want = act && finite && ok && small;
             const bool stop_bad = act && (!finite || !ok);
             const bool step = act && !stop_bad && !want;
-            if constexpr (COND) {
-                z = sel(step, fma(sgn, z, -dz), z);
-                fl = (want && (fl & 8) != 0) ? (fl | 16) : fl;
-                fl &= ~8;
-            } else {
-                z = sel(step, z - dz, z);
-            }
+            z = sel(step, z - dz, z);
             int nf = fl & ~1;
             // hasconverged is `resmaxabs < tol` even when solve() returned early because J was non-finite
             // or singular (src/solvers.jl:203,219-224); `small` is false for a NaN / inf residual
@@ -1578,16 +1602,81 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             ACME_T(TB_GLUE);
         } while ((actm = wv::ballot((fl & 1) != 0)) != 0ull);
         const bool accepted = (fl & 4) != 0;
+        lz = sel(accepted, z, lz);
+        lp = sel(accepted, target, lp);
+        return (fl & 6) != 0;
+    };
+
+    // solve(::SimpleSolver, p) on the condensed system.  cached_solve has run set_p(target), brought the condensation up
+    // to date, formed pf' and requested the origin's recorded multipliers (cmul).  mv: the potentiometers moved since
+    // the origin was taken -- the start is z0m (the full system's first-order extrapolation, cached_solve) and, like a
+    // start from an origin that was itself off the linear rows' subspace (osub), is evaluated `off` it.
+    // Flags (one integer per lane): 1 active, 2 hasconverged, 4 accepted, 8 this pass is `off`, 16 accepted off the
+    // subspace, 32 the lanes have re-learnt their order for this pass, 64 the last residual test.
+    auto base_solve_c = [&](double target, bool need, int &its, const double (&cmul)[NRr + 1], bool mv, double z0m) ACME_LAMBDA -> bool {
+        int fl = 0;
         if constexpr (COND) {
+            // z <- last_z - last_J \\ (last_Jp (p - last_p)) (src/solvers.jl:209-215) on the reduced system: the origin's Jq
+            // non-zeros times the change of pf', then its recorded elimination; the lanes of the linear rows hold
+            // (1, 0, 0) and -zp_L there and ride along: the start's z_L comes out of the same replay
+            double otp[2 * NT + 2];
+            constexpr int s0 = S::OS_TV & ~1;
+            sfor<0, (S::OS_PF + NT - s0 + 1) / 2>([&](auto cc) ACME_LAMBDA {
+                constexpr int c = 2 * decltype(cc)::value;
+                const wv::pair_t v = wv::ld2(&ojp[S::oslot(s0 + c)]);
+                otp[c] = v.lo;
+                otp[c + 1] = v.hi;
+            });
+            double t = 0.0;
+            sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
+                constexpr int tt = decltype(tc_)::value;
+                t = fma(otp[S::OS_TV - s0 + tt], pfr[tt] - otp[S::OS_PF - s0 + tt], t);
+            });
+            LU::template apply_loaded_from<NL, NR>(t, cmul);
+            z = sel(need, lz - t, z);
+            z = sel(need && mv, z0m, z);
+            fl = wv::keepi((need ? 1 : 0) | ((need && (osub != 0 || mv)) ? 8 : 0));
+            its = 0;
+            for (;;) {
+                unsigned long long actm = wv::ballot((fl & 1) != 0), redo = 0ull;
+                bool retry = false;
+                do {
+                    const bool act = (fl & 1) != 0, off = (fl & 8) != 0;
+                    bool small;
+                    double dz;
+                    const bool mine = lin_c(z, act, actm, false, small, dz, wv::ballot(off) != 0ull, off);
+                    retry = act && mine && (fl & 32) == 0;                 // first failure of the pivots in place: re-learn, repeat
+                    const bool stop_bad = act && mine && !retry;           // (src/solvers.jl:219-224: J singular or not finite)
+                    const bool want = act && !mine && small;
+                    const bool step = act && !mine && !want;
+                    its += (act && !retry) ? 1 : 0;
+                    z = sel(step, fma(sgn, z, -dz), z);
+                    int nf = fl;
+                    nf = stop_bad ? ((nf & ~3) | (small ? 2 : 0)) : nf;      // hasconverged is the residual test alone (:203)
+                    nf = want ? ((nf & ~1) | 4 | ((nf & 8) ? 16 : 0)) : nf;
+                    nf = (step && !(its < maxiter_v)) ? (nf & ~1) : nf;
+                    nf = retry ? (small ? (nf | 64) : (nf & ~64)) : (nf & ~(8 | 32));     // (a pass that went through: the next failure re-learns again)
+                    fl = wv::keepi(nf);
+                    redo = wv::ballot(retry);
+                    if (ACME_RARE(redo != 0ull)) break;
+                } while ((actm = wv::ballot((fl & 1) != 0)) != 0ull);
+                if (ACME_USUAL(redo == 0ull)) break;
+                const bool off = retry && (fl & 8) != 0;
+                const bool okp = relearn_c(z, retry, wv::ballot(off) != 0ull, off);
+                // (exactly singular S: setlhs! fails and the solve returns at once, src/solvers.jl:223-224 -- that pass counts)
+                its += (retry && !okp) ? 1 : 0;
+                fl = wv::keepi(retry ? (okp ? (fl | 32) : ((fl & ~3) | ((fl & 64) ? 2 : 0))) : fl);
+            }
+            const bool accepted = (fl & 4) != 0;
             // the accepted iterate's z_L: what the linear rows give for its z_N (the lanes' last "residual" is exactly
             // -(zp_L - W z_N)) -- unless it was accepted off the subspace, as it stood
             const bool offacc = (fl & 16) != 0;
             z = sel(accepted && islin && !offacc, -res, z);
             osub = accepted ? (offacc ? 1 : 0) : osub;
             opos = accepted ? pf[2] : opos;
+            lz = sel(accepted, z, lz);
+            lp = sel(accepted, target, lp);
         }
-        lz = sel(accepted, z, lz);
-        lp = sel(accepted, target, lp);
         return (fl & 6) != 0;
     };
 
@@ -1657,7 +1746,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             for (;;) {
                 if (ph != 0) LU::template load_stored_n<NR, S>(cmul, ojp);       // requested first: needed last
                 if (ph != 0 && back) sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pf[decltype(tc_)::value] = pft[decltype(tc_)::value]; });
-                else set_p(ph != 0 ? target : lp);
+                else set_p(wv::settle(ph != 0 ? target : lp));
                 if (ph != 0 && !back) {
                     // an origin to (re-)linearise, or potentiometers that moved since the origin was taken (opos is not
                     // known yet where the origin is stale: settled in phase 0): the origin's turn first
@@ -1676,10 +1765,15 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 if (ACME_USUAL(ph != 0)) break;
                 // ---- phase 0: pf, pf' and the condensation are the ORIGIN's ----
                 if (wv::ballot(reorig) != 0ull) {
-                    bool f0, k0, s0;
+                    bool s0;
                     double d0;
                     const bool roff = reorig && osub != 0;
-                    linearize(reorig ? lz : z, false, 0ull, reorig, f0, k0, s0, d0, wv::ballot(roff) != 0ull, roff);
+                    const unsigned long long roffany = wv::ballot(roff);
+                    const bool mine0 = lin_c(reorig ? lz : z, false, 0ull, reorig, s0, d0, roffany != 0ull, roff);
+                    if (ACME_RARE(wv::ballot(mine0 && reorig) != 0ull)) {      // the lanes' order fails at the origin: re-learn it there
+                        (void)relearn_c(reorig ? lz : z, mine0 && reorig, roffany != 0ull, roff);
+                        (void)lin_c(reorig ? lz : z, false, 0ull, reorig, s0, d0, roffany != 0ull, roff);
+                    }
                     opos = reorig ? pf[2] : opos;
                 }
                 mv = inst_any(need && islin && !(pft[2] == opos));
@@ -1725,7 +1819,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 }
                 ph = wv::opaque(1);
             }
-            c = base_solve(target, need, its, cmul, mv, z0m);
+            c = base_solve_c(target, need, its, cmul, mv, z0m);
         } else {
             if (ACME_RARE(wv::ballot(reorig))) {
                 set_p(lp);
@@ -1733,8 +1827,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 double d0;
                 linearize(reorig ? lz : z, false, 0ull, reorig, f0, k0, s0, d0);
             }
-            const double nocmul[NRr + 1] = {0.0};
-            c = base_solve(target, need, its, nocmul);
+            c = base_solve(target, need, its);
         }
         if (caching) {
             const bool keep = need && c && its > 5;

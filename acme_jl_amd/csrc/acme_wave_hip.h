@@ -375,6 +375,9 @@ ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // on the near side of a branch instead of being sunk below it)
 ACME_DEV double keep(double v) { asm volatile("" : "+v"(v)); return v; }
 ACME_DEV int keepi(int v) { asm volatile("" : "+v"(v)); return v; }
+// v, two wait states old: a value that DPP instructions may read at once (for sources the compiler's own code has just
+// produced -- a select, a copy -- in front of fused chains whose order among themselves is not fixed)
+ACME_DEV double settle(double v) { asm volatile("s_nop 1" : "+v"(v)); return v; }
 // a use of v here, nothing else (keeps its register allocated up to this point)
 ACME_DEV void touch(double v) { asm volatile("" : : "v"(v)); }
 // wave-uniform integer the optimiser must not reason about (stops it from cloning a big loop

@@ -248,6 +248,7 @@ ACME_DEV unsigned long long ballot(bool p) { return emu::ballot_bits(p, 500); }
 ACME_DEV int ffs32(int v) { return __builtin_ffs(v); }
 ACME_DEV double recip(double d) { if ((tid() & 63) == 0) emu::g_count_recip++; return 1.0 / d; }
 ACME_DEV double keep(double v) { return v; }
+ACME_DEV double settle(double v) { return v; }
 ACME_DEV int keepi(int v) { return v; }
 ACME_DEV void touch(double) {}
 ACME_DEV int opaque(int v) { return v; }
