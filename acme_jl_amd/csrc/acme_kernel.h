@@ -139,8 +139,11 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // the exponential's 16 constants in vector registers for the whole kernel (the non-RARE shapes have
     // them since their row constants went to LDS): no scalar loads per evaluate!, and 32 of the 102 scalar
     // registers back -- headline +1.5 %, config 4 +2.0 % (with 8 spilled registers), birdie +3.3 %
+    // (condensed shapes: the table in SCALAR registers again, fetched per evaluate! -- the condensation occupies 42
+    // vector registers for the whole launch, and with the table in 32 more the allocator spilled on the usual path:
+    // 1.01 against 1.11e9 on the headline, round 4)
 #ifndef ACME_COND_SCALAR_EXP
-#define ACME_COND_SCALAR_EXP 0
+#define ACME_COND_SCALAR_EXP 1
 #endif
     static constexpr bool EXPV = !RARE && !(NL_ > 0 && ACME_COND_SCALAR_EXP);
     static constexpr int OSTRIDE = GROUPS_PER_WAVE * (NN > 0 ? NN : 1);
@@ -346,7 +349,9 @@ template <int NN> struct RowLU {
     // are 2-way bank conflicts.  An odd slot count (NN even) leaves 1/pivot over: returned in dinv_out, the
     // caller stores it with the next slot.
     // GJHEAD / SAFE0: see Shape.
-    template <int NC, bool STORE, class SH, bool GJHEAD, bool SAFE0>
+    // SAFEALL: every step with the DPP wait states built in (cold callers whose registers the compiler shuffles between
+    // the steps: the condensation)
+    template <int NC, bool STORE, class SH, bool GJHEAD, bool SAFE0, bool SAFEALL = false>
     static ACME_DEV unsigned long long solve_inplace(double (&a)[NN > 0 ? NN : 1], double &b,
                                                      double (&c)[NC > 0 ? NC : 1], double *slab, bool keep,
                                                      double &dinv_out) {
@@ -379,7 +384,7 @@ template <int NN> struct RowLU {
                 sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA { rp[decltype(jc)::value - k - 1] = &a[decltype(jc)::value]; });
                 rp[NN - 1 - k] = &b;
                 sfor<0, NC>([&](auto jc) ACME_LAMBDA { rp[NN - k + decltype(jc)::value] = &c[decltype(jc)::value]; });
-                wv::gj_step<k, CNT, !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz, rp);
+                wv::gj_step<k, CNT, SAFEALL || !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz, rp);
             } else {
                 const double piv = wv::bcast16_ordered<k, !far_enough>(a[k]);
                 const double inv = wv::recip(piv);
@@ -449,7 +454,7 @@ template <int NN> struct RowLU {
     // parts: <0, NL> once per change of the potentiometer positions (wave_main: condense) and <NL, NN> in the
     // Newton loop, with the lanes 0 .. NL-1 riding along (their multipliers are not subject to the pivot
     // threshold: those rows are "above the pivot").  STORE: as in solve_inplace, K1 - K0 multipliers and 1 / pivot.
-    template <int K0, int K1, int NC, bool STORE, class SH>
+    template <int K0, int K1, int NC, bool STORE, class SH, bool SAFEALL = false>
     static ACME_DEV unsigned long long solve_range(double (&a)[NN > 0 ? NN : 1], double &b, double (&c)[NC > 0 ? NC : 1],
                                                    double *slab, bool keep, double &dinv_out) {
         constexpr int KN = K1 - K0;
@@ -467,7 +472,7 @@ template <int NN> struct RowLU {
             sfor<k + 1, NN>([&](auto jc) ACME_LAMBDA { rp[decltype(jc)::value - k - 1] = &a[decltype(jc)::value]; });
             rp[NN - 1 - k] = &b;
             sfor<0, NC>([&](auto jc) ACME_LAMBDA { rp[NN - k + decltype(jc)::value] = &c[decltype(jc)::value]; });
-            wv::gj_step<k, CNT, !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz, rp);
+            wv::gj_step<k, CNT, SAFEALL || !far_enough>(a[k], dinv, pivlanes, nlm, vmx, frz, rp);
             if constexpr (STORE) rec[k - K0] = nlm;
         });
         b *= dinv;
@@ -912,8 +917,6 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     double crw = 0.0;                 // lanes < NL: -r w of the row (res = v + crw i), for cpos
     double cpos = (double)NAN;        // lanes < NL: the position the condensation was made for (NaN: none yet)
     double pfr[NT];                   // pf' = pfull + fq_L zp_L at this lane's q rows (lanes < NL: pfr[0] = -zp_L)
-    double pft[NT];                   // pfull of the solve's target, parked while the origin has its turn (cached_solve)
-    sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pft[decltype(tc_)::value] = 0.0; });
     if constexpr (COND)
         sfor<0, 3>([&](auto tc_) ACME_LAMBDA { sfor<0, NR>([&](auto jc) ACME_LAMBDA { cd[decltype(tc_)::value][decltype(jc)::value] = 0.0; }); });
     sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pfr[decltype(tc_)::value] = 0.0; });
@@ -1082,11 +1085,12 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             // exactly 1 for it, as the other path sets it; a model without any BJT in one of these shapes
             // pays ~20 wasted instructions per row evaluation, every other one saves a taken branch)
             if (S::EXP2 || ACME_USUAL(has_bjt)) {                     // sA/sB = 0: exp(0) = 1
-                exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
+                if constexpr (S::EXPV) exp_junction2(e[0] * sA, e[1] * sB, exA, exB, etv);
+                else exp_junction2(e[0] * sA, e[1] * sB, exA, exB, wv::load_exp_tab());     // (the Jacobian export of the condensed shapes)
             } else {
                 // (big shape: this path -- models without a BJT -- keeps the scalar table; on the register
                 // table it costs the two-exponential path 4 spilled registers and 8 % of its speed)
-                if constexpr (!S::MULT) exA = exp_junction(e[0] * sA, etv);
+                if constexpr (!S::MULT && S::EXPV) exA = exp_junction(e[0] * sA, etv);
                 else exA = exp_junction(e[0] * sA);
                 exB = 1.0;
             }
@@ -1164,7 +1168,6 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         if constexpr (COND) {       // the row's reduced pfull entries and its rows of the condensation move along
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
                 pfr[decltype(tc_)::value] = wv::shfl16(pfr[decltype(tc_)::value], orig);
-                pft[decltype(tc_)::value] = wv::shfl16(pft[decltype(tc_)::value], orig);
             });
             sfor<0, 3>([&](auto tc_) ACME_LAMBDA {
                 sfor<0, NR>([&](auto jc) ACME_LAMBDA { cd[decltype(tc_)::value][decltype(jc)::value] = wv::shfl16(cd[decltype(tc_)::value][decltype(jc)::value], orig); });
@@ -1222,19 +1225,34 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // (then: the reference's partial pivoting among them, once).
     auto condense = [&](bool upd) ACME_LAMBDA {
         if constexpr (COND) {
-            double fqv[NT][NNr + 1], al[NNr], c6[NLr], hw = 0.0;
+            // (one term's rows at a time, the results selected into cd as they come: the whole of it at once needed
+            // ~180 registers on top of what the kernel holds, and the allocator paid for that on the usual path)
+            auto load_fq_row = [&](auto tc_, auto &row) ACME_LAMBDA {
+                constexpr int t = decltype(tc_)::value;
+                sfor<0, (NN + 1) / 2>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const wv::pair_t v = wv::ld2(&Ms[L.fqr + L.gat(t, j, 0, NN) + 2 * grow]);
+                    row[j] = v.lo;
+                    row[j + 1] = v.hi;
+                });
+            };
+            double al[NNr], c6[NLr], hw = 0.0;
             int tries = 0;
             for (;;) {
                 tries = wv::opaque(tries);
-                load_fq_rows(fqv);
                 // A_L row = Jq row * fq of a potentiometer half: (g0, h w, .) (acme_common.h: UnifiedRowConst)
                 const wv::pair_t h_ = wv::ld2(&rd.rc[3 * 2 * GROUP]), g01 = wv::ld2(&rd.rc[4 * 2 * GROUP]),
                                  g2w0 = wv::ld2(&rd.rc[5 * 2 * GROUP]), w1_ = wv::ld2(&rd.rc[6 * 2 * GROUP]);
                 hw = h_.lo * fma(w1_.lo, pf[2], g2w0.hi);
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA {
-                    constexpr int j = decltype(jc)::value;
-                    al[j] = fma(hw, fqv[1][j], g01.lo * fqv[0][j]);
-                });
+                {
+                    double r0[NNr + 1], r1[NNr + 1];
+                    load_fq_row(std::integral_constant<int, 0>{}, r0);
+                    load_fq_row(std::integral_constant<int, 1>{}, r1);
+                    sfor<0, NN>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        al[j] = fma(hw, r1[j], g01.lo * r0[j]);
+                    });
+                }
                 // A_LL^-1 (rows in the lanes): Gauss-Jordan of [A_LL | I]
                 double a6[NLr], b6 = 0.0, d6;
                 sfor<0, NL>([&](auto kc) ACME_LAMBDA {
@@ -1242,7 +1260,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     a6[k] = al[k];
                     c6[k] = lig_eq<k>() ? 1.0 : 0.0;
                 });
-                unsigned long long viol = LUL::template solve_inplace<NL, false, S, true, true>(a6, b6, c6, nullptr, false, d6);
+                unsigned long long viol = LUL::template solve_inplace<NL, false, S, true, true, true>(a6, b6, c6, nullptr, false, d6);
                 viol &= wv::ballot(islin && upd);
                 if (ACME_USUAL(viol == 0ull || tries != 0)) break;
                 const bool mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
@@ -1256,23 +1274,24 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             }
             // W (lanes < NL) and fq' (the others, one pass per term of their rows): the elimination of the linear rows
             // with every row's columns NL .. NN-1 riding along
-            double nd[3][NRr];
             sfor<0, 3>([&](auto tc_) ACME_LAMBDA {
                 constexpr int t = decltype(tc_)::value;
-                double a_[NNr], b_ = 0.0, none[1] = {0.0}, dv;
-                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a_[decltype(jc)::value] = islin ? al[decltype(jc)::value] : fqv[t][decltype(jc)::value]; });
-                (void)LU::template solve_range<0, NL, 0, false, S>(a_, b_, none, nullptr, false, dv);
-                sfor<0, NR>([&](auto jc) ACME_LAMBDA { nd[t][decltype(jc)::value] = islin ? a_[NL + decltype(jc)::value] * dv : a_[NL + decltype(jc)::value]; });
-            });
-            sfor<0, NR>([&](auto jc) ACME_LAMBDA {
-                constexpr int j = decltype(jc)::value;
-                const double l1 = j < NL ? c6[j < NL ? j : 0] : 0.0;
-                cd[0][j] = upd ? nd[0][j] : cd[0][j];
-                cd[1][j] = upd ? (islin ? l1 : nd[1][j]) : cd[1][j];
-                cd[2][j] = upd ? (islin ? 0.0 : nd[2][j]) : cd[2][j];
+                double a_[NNr + 1], b_ = 0.0, none[1] = {0.0}, dv;
+                load_fq_row(tc_, a_);
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { a_[decltype(jc)::value] = islin ? al[decltype(jc)::value] : a_[decltype(jc)::value]; });
+                double ar[NNr];
+                sfor<0, NN>([&](auto jc) ACME_LAMBDA { ar[decltype(jc)::value] = a_[decltype(jc)::value]; });
+                (void)LU::template solve_range<0, NL, 0, false, S, true>(ar, b_, none, nullptr, false, dv);
+                sfor<0, NR>([&](auto jc) ACME_LAMBDA {
+                    constexpr int j = decltype(jc)::value;
+                    const double nv = t == 0 ? (islin ? ar[NL + j] * dv : ar[NL + j])
+                                             : (islin ? (t == 1 && j < NL ? c6[j < NL ? j : 0] : 0.0) : ar[NL + j]);
+                    cd[t][j] = upd ? nv : cd[t][j];
+                });
             });
             crw = upd ? hw : crw;
             cpos = upd ? pf[2] : cpos;
+            ACME_T(TB_GJ0);     // (the timing builds' "GJ<0>" bucket: unused by the condensed kernel's Newton loop)
         }
     };
     // pf (set_p) -> pf' for the current condensation; lanes < NL: pfr[0] = -zp_L = A_LL^-1 b_L
@@ -1364,6 +1383,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         bool mine = false;
         if constexpr (COND) {
             evaluate_c(zz, offany, off);
+            ACME_T(TB_EVAL);
             unsigned long long big = wv::ballot(!(fabs(res) < tol_v)) & rows4(((1ull << NN) - 1ull) & ~((1ull << NL) - 1ull));
             if (ACME_RARE(offany)) big |= wv::ballot(off && islin && !(fabs(lres) < tol_v));     // (off the subspace, the linear rows count)
             small = ((big >> (grp * GROUP)) & 0xFFFFull) == 0ull;
@@ -1375,6 +1395,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             unsigned long long viol = LU::template solve_range<NL, NN, 0, true, S>(a, dz, none, ojp, want && lig < NN, dinv);
             viol &= actm | wv::ballot(force);
             mine = ((viol >> (grp * GROUP)) & 0xFFFFull) != 0ull;
+            ACME_T(TB_GJP);
             if (recording) {
                 if (want && !mine && lig < NN)
                     sfor<(NR + 1) / 2, S::OSLOTS / 2>([&](auto cc) ACME_LAMBDA {
@@ -1389,6 +1410,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     });
                 stale = want ? (mine ? 1 : 0) : stale;
             }
+            ACME_T(TB_STORE);
         }
         return mine;
     };
@@ -1404,6 +1426,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             adopt(orig);
             stale = who ? 1 : stale;
             okp = who ? okp : true;
+            ACME_T(TB_PIVOT);
         }
         return okp;
     };
@@ -1637,6 +1660,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             z = sel(need && mv, z0m, z);
             fl = wv::keepi((need ? 1 : 0) | ((need && (osub != 0 || mv)) ? 8 : 0));
             its = 0;
+            ACME_T(TB_SETUP);
             for (;;) {
                 unsigned long long actm = wv::ballot((fl & 1) != 0), redo = 0ull;
                 bool retry = false;
@@ -1658,6 +1682,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     nf = retry ? (small ? (nf | 64) : (nf & ~64)) : (nf & ~(8 | 32));     // (a pass that went through: the next failure re-learns again)
                     fl = wv::keepi(nf);
                     redo = wv::ballot(retry);
+                    ACME_T(TB_GLUE);
                     if (ACME_RARE(redo != 0ull)) break;
                 } while ((actm = wv::ballot((fl & 1) != 0)) != 0ull);
                 if (ACME_USUAL(redo == 0ull)) break;
@@ -1745,14 +1770,12 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             int ph = wv::opaque(1);
             for (;;) {
                 if (ph != 0) LU::template load_stored_n<NR, S>(cmul, ojp);       // requested first: needed last
-                if (ph != 0 && back) sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pf[decltype(tc_)::value] = pft[decltype(tc_)::value]; });
-                else set_p(wv::settle(ph != 0 ? target : lp));
+                set_p(wv::settle(ph != 0 ? target : lp));
                 if (ph != 0 && !back) {
                     // an origin to (re-)linearise, or potentiometers that moved since the origin was taken (opos is not
                     // known yet where the origin is stale: settled in phase 0): the origin's turn first
                     mvpre = inst_any(need && islin && !(pf[2] == opos));
                     if (ACME_RARE(wv::ballot(reorig || mvpre) != 0ull)) {
-                        sfor<0, NT>([&](auto tc_) ACME_LAMBDA { pft[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
                         ph = wv::opaque(0);
                         back = true;
                         continue;
@@ -1776,6 +1799,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     }
                     opos = reorig ? pf[2] : opos;
                 }
+                // (the target's pfull in the lanes' PRESENT order -- an adoption may just have changed it)
+                double pfo[3], pft[3];
+                sfor<0, 3>([&](auto tc_) ACME_LAMBDA { pfo[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
+                set_p(wv::settle(target));
+                sfor<0, 3>([&](auto tc_) ACME_LAMBDA { pft[decltype(tc_)::value] = pf[decltype(tc_)::value]; pf[decltype(tc_)::value] = pfo[decltype(tc_)::value]; });
                 mv = inst_any(need && islin && !(pft[2] == opos));
                 if (wv::ballot(mv) != 0ull) {
                     // The potentiometers moved since the origin was taken: z0 = last_z - last_J \ (last_Jp (p - last_p))

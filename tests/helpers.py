@@ -140,3 +140,28 @@ def rare_per_instance_case(n=4):
     u = np.stack([u1 * (1 + 0.2 * k) for k in range(n)])[:, None, :]
     return models, u
 
+
+
+def moving_pot_inputs(N, T, seed=5):
+    """superover_var inputs [N, 4, T] whose three potentiometers move EVERY sample (ramps, slow and fast wobbles,
+    jumps), instance 0 being test/runtests.jl:778 verbatim (its first sample sits on the singular drive = 1.0
+    corner)."""
+    rng = np.random.default_rng(seed)
+    n = np.arange(T)
+    u = np.zeros((N, 4, T))
+    u[:, 0] = rng.uniform(0.3, 1.0, N)[:, None] * sine(T)[None]
+    for i in range(N):
+        for k in range(3):
+            kind = (i + k) % 4
+            a, b = rng.uniform(0.02, 0.5), rng.uniform(0.5, 0.98)
+            if kind == 0:
+                pot = np.linspace(a, b, T)
+            elif kind == 1:
+                pot = np.linspace(b, a, T)
+            elif kind == 2:
+                pot = a + (b - a) * (0.5 + 0.5 * np.sin(2 * np.pi * n / rng.uniform(13, 400)))
+            else:
+                pot = np.where((n // rng.integers(7, 60)) % 2 == 0, a, b) + 1e-3 * np.sin(n / 3.0)
+            u[i, 1 + k] = pot
+    u[0] = np.stack([sine(T), np.linspace(1, 0, T), np.linspace(0, 1, T), np.linspace(1, 0, T)])
+    return u

@@ -577,3 +577,57 @@ def test_emulated_lane_kernel_cache_layout(emu_lib, monkeypatch):
     z, conv, its = r.solve(np.zeros((4, 2)))
     assert conv.all() and its.tolist() == [1, 1, 1, 1]
     assert np.array_equal(z, np.tile(m.subs[0].init_z, (4, 1)))
+
+
+def test_emulated_condensed_kernel_is_selected_and_exact(emu_lib, monkeypatch):
+    """The headline model runs in the CONDENSED kernel (its 6 potentiometer rows eliminated once per change of the
+    pot positions, Newton on the other 7) and walks the oracle's Newton path: identical iteration totals, outputs
+    to rounding -- with fixed pots, with pots that move every sample (incl. the reference's own test input,
+    test/runtests.jl:778, whose first sample is the singular drive = 1.0 corner), on both solver stacks; the plain
+    13 x 13 kernel (ACME_CONDENSE=0) still does the same."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from helpers import HS, RTOL_SAME, moving_pot_inputs
+    for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+        m = load("superover_var", solver)
+        for u in (sweep_inputs("superover_var", 5, 160, seed=2), moving_pot_inputs(4, 220)):
+            yref, its = oracle_run(m, u, cache_limit=lim)
+            for cond in ("1", "0"):
+                monkeypatch.setenv("ACME_CONDENSE", cond)
+                r = emu_runner(emu_lib, m, u.shape[0])
+                y = r.run(u, check=False)
+                assert_close(y, yref, rtol=RTOL_SAME)
+                assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (solver, cond)
+
+
+def test_emulated_condensed_state_solve_and_jacobian(emu_lib, monkeypatch):
+    """The condensed kernel keeps z in a permuted basis internally: state get / set, acme_batch_solve and the
+    extrapolation Jacobian speak the caller's; a run split at a launch boundary -- with the state read and written
+    back in between -- repeats the one-launch run bit for bit, and the condensed and plain kernels agree."""
+    from helpers import HS
+    m = load("superover_var", HS)
+    u = sweep_inputs("superover_var", 3, 120, seed=4)
+    out = {}
+    for cond in ("1", "0"):
+        monkeypatch.setenv("ACME_CONDENSE", cond)
+        y1 = emu_runner(emu_lib, m, 3).run(u)
+        r = emu_runner(emu_lib, m, 3)
+        ya = r.run(u[:, :, :50])
+        yb = r.run(u[:, :, 50:])
+        assert np.array_equal(y1, np.concatenate([ya, yb], axis=2))
+        x, p, z = r.get_state()
+        jac = r.get_extrapolation_jacobian()
+        zs, conv, its = r.solve(p * (1 + 1e-9))       # (next to the origin: a plain Newton solve, no homotopy episode)
+        out[cond] = (y1, x, p, z, jac, zs, conv, its)
+        # a state written back from outside is not trusted to satisfy the linear rows: same results to rounding
+        r2 = emu_runner(emu_lib, m, 3)
+        r2.run(u[:, :, :50])
+        x2, p2, z2 = r2.get_state()
+        r2.set_state(x=x2, p=p2, z=z2)
+        yb2 = r2.run(u[:, :, 50:])
+        assert_close(yb2, yb, rtol=1e-12)
+    names = ("y", "x", "p", "z", "jac", "z of solve", "converged", "iterations")
+    for name, a, b in zip(names, out["1"], out["0"]):      # (small entries of the Jacobian are differences of large ones)
+        b = np.asarray(b, dtype=float)
+        # the solve from an arbitrary p stops at the residual tolerance: two eliminations, two last iterates
+        rtol = 1e-6 if name == "z of solve" else 1e-9
+        np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=rtol, atol=1e-12 + 1e-12 * np.abs(b).max(), err_msg=name)

@@ -222,3 +222,31 @@ def test_config4_full_width(hip_lib):
         worst = max(worst, assert_close(yh[k:k + 1], yref))
     print(f"config 4 full width: worst spot error vs exact per-instance oracle models {worst:.2e}")
     assert float((y1[0] - y1[1]).abs().max()) > 1e-6
+
+
+def test_condensed_kernel_moving_pots_many_instances(hip_lib, monkeypatch):
+    """The headline model's CONDENSED kernel with all three potentiometers moving EVERY sample (ramps, wobbles,
+    jumps; instance 0 = test/runtests.jl:778 verbatim, first sample on the singular drive = 1.0 corner), 96
+    instances x 1000 samples, both solver stacks: outputs at RTOL of the oracle (measured: rounding level) and
+    iteration totals within 1 % of it per instance (measured: identical) -- and the same from the plain 13 x 13
+    kernel (ACME_CONDENSE=0)."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL, moving_pot_inputs
+    N, T = 96, 1000
+    u = moving_pot_inputs(N, T)
+    for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+        yref, its, warn = oracle_parallel("superover_var", solver, u, cache_limit=lim)
+        for cond in ("1", "0"):
+            monkeypatch.setenv("ACME_CONDENSE", cond)
+            m = load("superover_var", solver)
+            r = ModelRunner(m, N, lib=hip_lib)
+            y = np.concatenate([r.run(u[:, :, :333], check=False), r.run(u[:, :, 333:], check=False)], axis=2)
+            ra = r.report_arrays()
+            err = rel_err(y, yref)
+            dev = np.abs(ra["iters_total"] - its) / its
+            print(f"moving pots, {solver}, condensed={cond}: rel err {err:.2e}, iteration totals {ra['iters_total'].sum()} vs "
+                  f"{its.sum()} (worst instance {dev.max():.2e}), warnings {ra['n_warn'].sum()} vs {warn.sum()}")
+            assert err <= RTOL
+            assert dev.max() <= 0.01
+            assert (ra["first_nonfinite"] < 0).all() and ra["n_warn"].sum() <= warn.sum() + 1
