@@ -1332,8 +1332,6 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 urc[2 * p] = v.lo;
                 urc[2 * p + 1] = v.hi;
             });
-            wv::ExpTab est;             // (scalar-table shapes: requested here, needed after the q chains)
-            if constexpr (!S::EXPV) est = wv::load_exp_tab_begin();
             double e[NT], de[NT];       // de: full q minus reduced q' (off only)
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pfr[decltype(tc_)::value]; });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {
@@ -1358,10 +1356,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             }
             double exA, exB;
             if constexpr (S::EXPV) exp_junction2(e[0] * urc[0], e[1] * urc[1], exA, exB, etv);
-            else {
-                wv::exp_tab_ready(est);
-                exp_junction2(e[0] * urc[0], e[1] * urc[1], exA, exB, est);
-            }
+            else exp_junction2(e[0] * urc[0], e[1] * urc[1], exA, exB, wv::load_exp_tab());
             eval_row_unified_c<NT>(urc, e, exA, exB, res, tv);
             sfor<0, NR>([&](auto jc) ACME_LAMBDA {
                 constexpr int j = decltype(jc)::value;

@@ -416,17 +416,6 @@ ACME_DEV double clamp_s(double k, double lo, double hi) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "s"(hi));
     return r;
 }
-// ... in two halves: the loads issued here, waited for there -- their latency (a few hundred cycles from the scalar
-// cache) behind whatever the caller does in between.  The table registers are outputs of the first statement and
-// in / outputs of the second: nothing reads them before the wait, nothing reuses them in between.
-ACME_DEV ExpTab load_exp_tab_begin() {
-    ExpTab t;
-    const double *p = acme_exp_tab;
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
-                 : "=&s"(t.lo8), "=&s"(t.hi8) : "s"(p));
-    return t;
-}
-ACME_DEV void exp_tab_ready(ExpTab &t) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t.lo8), "+s"(t.hi8)); }
 ACME_DEV ExpTab load_exp_tab() {
     ExpTab t;
     const double *p = acme_exp_tab;

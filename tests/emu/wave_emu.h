@@ -265,8 +265,6 @@ ACME_DEV ExpTab load_exp_tab() {
                    2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03,
                    8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, -2100.0, 2100.0}};
 }
-ACME_DEV ExpTab load_exp_tab_begin() { return load_exp_tab(); }
-ACME_DEV void exp_tab_ready(ExpTab &) {}
 template <class T> ACME_DEV const T *uniform_ro(const T *p) { return p; }
 struct pair_t { double lo, hi; };
 ACME_DEV pair_t ld2(const double *p) { return pair_t{p[0], p[1]}; }
