@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
-    "acme_batch_run_async", "acme_batch_wait",
+    "acme_batch_run_async", "acme_batch_wait", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
@@ -80,6 +80,10 @@ def _preload_torch_hip_runtime():
         except OSError:
             return None
     return None
+
+
+# acme_progress_fn(user, samples_done, samples_total)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_longlong, C.c_longlong)
 
 
 class Library:
@@ -112,6 +116,8 @@ class Library:
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_run_async.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_wait.argtypes = [vp]
+        L.acme_batch_release_host_buffers.argtypes = [vp]
+        L.acme_batch_set_progress_callback.argtypes = [vp, PROGRESS_FN, vp]
         L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_get_extrapolation_jacobian.argtypes = [vp, C.c_int, dp, C.c_int, vp]
         L.acme_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -187,6 +193,12 @@ class _ModelHandle:
             self.h = None
 
 
+def _print_progress(done, total):
+    import sys
+    sys.stderr.write("\rrun!: %3d %% (%d / %d samples)%s" % (100 * done // max(total, 1), done, total, "\n" if done >= total else ""))
+    sys.stderr.flush()
+
+
 class ModelRunner:
     """``ModelRunner(model, showprogress)`` for ``n_instances`` parallel copies of a model.
 
@@ -204,7 +216,9 @@ class ModelRunner:
             raise AcmeError("no HIP device available; acme_jl_amd has no CPU fallback")
         self.model = model
         self.n = int(n_instances)
-        self.showprogress = showprogress   # accepted for API parity; progress is not shown
+        # ``showprogress``: True prints a progress line per time slice of a host-buffer run (the reference wraps
+        # its sample loop in @showprogress, src/ACME.jl:587-604,653); a callable gets (samples_done, samples_total)
+        self.showprogress = showprogress
         self._mh = _ModelHandle(self.lib, model)
         o = Options()
         self.lib.L.acme_default_options(C.byref(o))
@@ -215,8 +229,17 @@ class ModelRunner:
         self.lib.check(self.lib.L.acme_batch_create(self._mh.h, self.n, C.byref(o), C.byref(h)))
         self.h = h
         self._warned = 0
+        self._progress_cb = None
+        if showprogress:
+            fn = showprogress if callable(showprogress) else _print_progress
+            self._progress_cb = PROGRESS_FN(lambda user, done, total: fn(int(done), int(total)))    # (kept alive here)
+            self.lib.check(self.lib.L.acme_batch_set_progress_callback(self.h, self._progress_cb, None))
         if models is not None:
             self.set_models(0, models)
+
+    def release_host_buffers(self):
+        """Un-page-lock the arrays of the last host-buffer run (``acme_batch_release_host_buffers``)."""
+        self.lib.check(self.lib.L.acme_batch_release_host_buffers(self.h))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -304,6 +304,38 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     return out
 
 
+def host_buffer_leg(runner, u, N, T, model):
+    """run! through host buffers (see main): instance*samples/s of the first call (page-locks u and y), of the
+    following calls on the same arrays (steady state) and, on a second pair of arrays, from pageable memory."""
+    import ctypes as C
+    from acme_jl_amd.runner import ACME_MEM_HOST
+    dp = C.POINTER(C.c_double)
+    uh = u.cpu().numpy()                       # [N][T][nu]: the ABI's (and Julia's nu x T x N) layout
+    yh = np.empty((N, T, model.ny))
+
+    def call(ub, yb):
+        t0 = time.perf_counter()
+        runner.lib.check(runner.lib.L.acme_batch_run(runner.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
+        return time.perf_counter() - t0
+    out = {"bytes_in": int(uh.nbytes), "bytes_out": int(yh.nbytes)}
+    os.environ.pop("ACME_HOST_REGISTER", None)
+    t_first = call(uh, yh)
+    ts = [call(uh, yh) for _ in range(2)]
+    out.update(first_call_ms=1e3 * t_first, steady_ms=1e3 * min(ts), steady_value=N * T / min(ts),
+               first_call_value=N * T / t_first, y_abs_sum=float(np.abs(np.nan_to_num(yh)).sum()))
+    runner.release_host_buffers()
+    os.environ["ACME_HOST_REGISTER"] = "0"
+    try:
+        t_page = min(call(uh, yh) for _ in range(2))
+    finally:
+        os.environ.pop("ACME_HOST_REGISTER", None)
+    out.update(pageable_ms=1e3 * t_page, pageable_value=N * T / t_page,
+               note="acme_batch_run(ACME_MEM_HOST) on the timed batch, continuing the signal: time slices, copies "
+                    "overlapped with the kernel on a second stream; first call page-locks the caller's arrays, "
+                    "steady = the same arrays again, pageable = ACME_HOST_REGISTER=0")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +356,9 @@ def main():
                          "rank0 = every rank sends its y to rank 0 (grouped send/recv), allgather = RCCL all-gather; "
                          "default: rank0 when N > 1, none at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the host-buffer leg (config.value_host_buffers: run! through acme_batch_run(ACME_MEM_HOST), "
+                         "what the Julia binding calls)")
     ap.add_argument("--cpu-samples", type=int, default=None)
     args = ap.parse_args()
 
@@ -463,6 +498,13 @@ def main():
             assert torch.equal(full[rank * n_per_gpu:(rank + 1) * n_per_gpu].to(y.device), y)
         del full
 
+    # The host-buffer path -- acme_batch_run(ACME_MEM_HOST), what julia/ACMEHip.jl's run! calls with the caller's
+    # arrays (src/ACME.jl:650-664) -- on the same batch, continuing the signal (steady state): u and y in host memory,
+    # in time slices whose copies overlap the kernel.  First call: page-locks the arrays; steady: the same arrays again
+    # (a caller reusing its arrays); pageable: ACME_HOST_REGISTER=0.  Never `value`.
+    host = None
+    if world == 1 and not args.no_host_path:
+        host = host_buffer_leg(runner, u, n_per_gpu, T, model)
     if rank == 0:
         units = world * n_per_gpu * T * args.steps
         value = units / elapsed
@@ -504,6 +546,8 @@ def main():
                 "gather": gather_mode, "gather_ms": gather_ms, "gathered_shape": gathered_shape,
                 "value_incl_gather": (units / (elapsed + args.steps * gather_ms * 1e-3)) if gather_ms is not None else None,
                 "cold_first_step_ms": cold_ms,
+                "value_host_buffers": host["steady_value"] if host else None,
+                "host_buffers": host,
                 "timed_steps_note": "the timed steps continue the signal of the warm-up steps: warm solver state and "
                                     "solution caches (steady state); cold_first_step_ms is the first step of the fresh batch",
                 "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,

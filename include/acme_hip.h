@@ -142,6 +142,20 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
  * hipStream_t to launch on (NULL = default stream); the call is then asynchronous. */
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
                    void *stream);
+/* Host-buffer runs page-lock the caller's u and y for DMA (copies from pageable memory run at less than
+ * half the bus rate, and page-locking costs about one copy): the last range of each direction stays
+ * locked, so that a caller reusing its arrays across run! calls -- what the in-place run!(runner, y, u)
+ * is for, src/ACME.jl:650-664 -- pays once.  The ranges are released when other arrays come, by
+ * acme_batch_destroy, and by this call (before the caller frees or resizes its arrays while the batch
+ * lives on).  Memory that cannot be locked is copied from as it is.  ACME_HOST_REGISTER=0 in the
+ * environment disables the locking. */
+int acme_batch_release_host_buffers(acme_batch *b);
+/* @showprogress of run!(runner, y, u) (src/ACME.jl:587-604,653): `fn(user, samples_done, samples_total)`
+ * is called on the calling thread (the worker thread of an asynchronous run) after every time slice of a
+ * host-buffer run -- 8 per run of 4096+ samples -- and once at the end of any other run.  fn = NULL
+ * removes it.  The callback must not call into the batch. */
+typedef void (*acme_progress_fn)(void *user, long long samples_done, long long samples_total);
+int acme_batch_set_progress_callback(acme_batch *b, acme_progress_fn fn, void *user);
 
 /* acme_batch_run without blocking the caller: the same run on a worker thread of the library (a
  * host-buffer run drives its time-slice pipeline from there).  ONE host thread can thereby keep one

@@ -30,10 +30,11 @@ module ACMEHip
 using ACME
 using ACME: DiscreteModel, NonlinearSolver, ParametricNonLinEq
 using LinearAlgebra: I
+import ProgressMeter
 import ACME: run!, solve, hasconverged, needediterations, set_resabstol!,
              get_extrapolation_origin, set_extrapolation_origin, get_extrapolation_jacobian
 
-export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table
+export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, release_host_buffers!
 
 const lib = get(ENV, "ACME_HIP_LIB", "libacme_hip.so")
 
@@ -201,20 +202,44 @@ mutable struct BatchRunner
     h::Ptr{Cvoid}
     mh::ModelHandle
     warned::Int
+    progress::Base.RefValue{Any}      # the ProgressMeter.Progress of the run in flight (showprogress = true)
+    showprogress::Bool
+end
+
+# @showprogress of run!(runner, y, u) (src/ACME.jl:587-604,653): the library reports after every time slice of a
+# host-buffer run through a C callback; `user` points at the runner's `progress` cell (kept alive by the runner)
+function progress_trampoline(user::Ptr{Cvoid}, done::Clonglong, total::Clonglong)::Cvoid
+    p = unsafe_pointer_to_objref(user)::Base.RefValue{Any}
+    p[] === nothing || ProgressMeter.update!(p[], Int(done))
+    return nothing
 end
 
 function BatchRunner(model::DiscreteModel, n::Integer; device::Integer=-1,
                      solver=isempty(model.solvers) ? ACME_SOLVER_HOMOTOPY : solver_id(typeof(model.solvers[1])),
-                     per_instance_matrices::Bool=false)
+                     per_instance_matrices::Bool=false, showprogress::Bool=false)
     mh = ModelHandle(model)
     opts = Ref(AcmeOptions(solver, 1e-10, 500, device, per_instance_matrices ? 1 : 0))
     b = Ref{Ptr{Cvoid}}()
     check(ccall((:acme_batch_create, lib), Cint, (Ptr{Cvoid}, Clonglong, Ref{AcmeOptions}, Ref{Ptr{Cvoid}}),
                 mh.h, n, opts, b))
-    r = BatchRunner(model, n, b[], mh, 0)
+    r = BatchRunner(model, n, b[], mh, 0, Ref{Any}(nothing), showprogress)
     finalizer(r -> ccall((:acme_batch_destroy, lib), Cvoid, (Ptr{Cvoid},), r.h), r)
+    if showprogress
+        cb = @cfunction(progress_trampoline, Cvoid, (Ptr{Cvoid}, Clonglong, Clonglong))
+        check(ccall((:acme_batch_set_progress_callback, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    r.h, cb, pointer_from_objref(r.progress)))
+    end
     return r
 end
+
+"""
+    release_host_buffers!(runner)
+
+`run!` page-locks `u` and `y` for DMA and keeps the last pair locked (re-used arrays pay once); call this before
+freeing or resizing them while the runner lives on.
+"""
+release_host_buffers!(r::BatchRunner) =
+    (check(ccall((:acme_batch_release_host_buffers, lib), Cint, (Ptr{Cvoid},), r.h)); r)
 
 """
     set_models!(runner, first, models)
@@ -268,9 +293,11 @@ end
 
 function run!(r::BatchRunner, y::Array{Float64,3}, u::Array{Float64,3})
     checkiosizes(r.model, r.n, y, u)
-    check(ccall((:acme_batch_run, lib), Cint,
+    r.showprogress && (r.progress[] = ProgressMeter.Progress(size(u, 2)))     # (as @showprogress for n = 1:size(u, 2))
+    GC.@preserve r check(ccall((:acme_batch_run, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Clonglong, Cint, Ptr{Cvoid}),
                 r.h, u, y, size(u, 2), ACME_MEM_HOST, C_NULL))
+    r.showprogress && (ProgressMeter.finish!(r.progress[]); r.progress[] = nothing)
     return checkreports!(r)
 end
 

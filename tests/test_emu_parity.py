@@ -631,3 +631,26 @@ def test_emulated_condensed_state_solve_and_jacobian(emu_lib, monkeypatch):
         # the solve from an arbitrary p stops at the residual tolerance: two eliminations, two last iterates
         rtol = 1e-6 if name == "z of solve" else 1e-9
         np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=rtol, atol=1e-12 + 1e-12 * np.abs(b).max(), err_msg=name)
+
+
+def test_emulated_progress_callback_and_host_buffer_release(emu_lib):
+    """@showprogress of run!(runner, y, u) (src/ACME.jl:587-604,653) as a callback after every time slice of a
+    host-buffer run, and the page-locked caller arrays being released on demand (the emulator backend only counts
+    the ranges; the bookkeeping is the library's)."""
+    m = load("diodeclipper")
+    seen = []
+    from acme_jl_amd.runner import ModelRunner
+    r = ModelRunner(m, 3, lib=emu_lib, showprogress=lambda done, total: seen.append((done, total)))
+    T = 4500                                   # >= 4096: sliced
+    u = sweep_inputs("diodeclipper", 3, T)
+    y = r.run(u)
+    assert seen and seen[-1] == (T, T)
+    dones = [d for d, _ in seen]
+    assert dones == sorted(dones) and len(seen) >= 2 and all(t == T for _, t in seen)
+    yref, _ = oracle_run(m, u)
+    assert_close(y, yref, rtol=1e-12)
+    seen.clear()
+    r.run(u[:, :, :100])                       # a short run reports once, at its end
+    assert seen == [(100, 100)]
+    r.release_host_buffers()
+    r.release_host_buffers()                   # idempotent

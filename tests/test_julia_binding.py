@@ -85,6 +85,7 @@ JULIA_FOR = {
     "const acme_model*const*": {"Ptr{Ptr{Cvoid}}"},
     "const acme_options*": {"Ref{AcmeOptions}", "Ptr{AcmeOptions}"}, "acme_options*": {"Ref{AcmeOptions}", "Ptr{AcmeOptions}"},
     "acme_report*": {"Ptr{AcmeReport}", "Ref{AcmeReport}"},
+    "acme_progress_fn": {"Ptr{Cvoid}"},      # a C function pointer: what @cfunction returns
 }
 JULIA_RET = {"int": "Cint", "void": "Cvoid", "const char*": "Cstring"}
 
