@@ -152,7 +152,7 @@ int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int m
 int acme_batch_release_host_buffers(acme_batch *b);
 /* @showprogress of run!(runner, y, u) (src/ACME.jl:587-604,653): `fn(user, samples_done, samples_total)`
  * is called on the calling thread (the worker thread of an asynchronous run) after every time slice of a
- * host-buffer run -- 8 per run of 4096+ samples -- and once at the end of any other run.  fn = NULL
+ * host-buffer run -- up to 24 per run of 4096+ samples -- and once at the end of any other run.  fn = NULL
  * removes it.  The callback must not call into the batch. */
 typedef void (*acme_progress_fn)(void *user, long long samples_done, long long samples_total);
 int acme_batch_set_progress_callback(acme_batch *b, acme_progress_fn fn, void *user);
