@@ -223,6 +223,7 @@ static inline int copy2d_d2h_async(void *d, size_t dpitch, const void *s, size_t
 static int g_registered = 0;     // (ranges currently "page-locked": the emulator only counts them, tests read the count)
 static inline int host_register(void *, size_t) { ++g_registered; return 0; }
 static inline int host_unregister(void *) { --g_registered; return 0; }
+static inline int host_device_pointer(void **d, void *h) { *d = h; return 0; }
 static inline int stream_create_nonblocking(stream_t *st) { *st = nullptr; return 0; }
 static inline int stream_destroy(stream_t) { return 0; }
 static inline int device_sync() { return 0; }
