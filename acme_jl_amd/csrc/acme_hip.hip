@@ -69,6 +69,12 @@ static const std::vector<KernelEntry> &kernel_table() {
     return t;
 }
 
+// the generic kernel (acme_generic.h): one lane per instance
+__global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (i < A.n_inst) gen_main(A, i);
+}
+
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
         if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub && k.d.nl == d.nl)
@@ -119,6 +125,10 @@ static inline int event_destroy(event_t e) { return (int)hipEventDestroy(e); }
 static inline int event_record(event_t e, stream_t st) { return (int)hipEventRecord(e, st); }
 static inline int event_sync(event_t e) { return (int)hipEventSynchronize(e); }
 static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)hipEventElapsedTime(ms, a, b); }
+static inline int launch_generic(const GArgs &A, stream_t st) {
+    hipLaunchKernelGGL(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
+    return (int)hipGetLastError();
+}
 static inline std::mutex *run_mutex() { return nullptr; }     // HIP: runs of distinct batches are concurrent
 }  // namespace be
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "acme_common.h"
+#include "acme_generic.h"
 #include "acme_shapes.h"
 
 namespace acme {
@@ -602,6 +603,99 @@ inline bool pack_model(const HostModel &m_in, Packed &P, std::string &err, const
             }
         }
     }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The generic kernel's model (acme_generic.h): any dimensions, any number of sub-problems.  Matrices column-major as
+// the caller handed them over; one row descriptor per residual row, 16 rows to a block of the row tables.
+// ---------------------------------------------------------------------------------------------------------------
+struct PackedGeneric {
+    GenHeader H{};
+    std::vector<double> image, rowc, init_state;
+    std::vector<int> rowi;
+};
+inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err) {
+    GenHeader &H = G.H;
+    H = GenHeader{};
+    if ((int)m.subs.size() > GEN_MAX_SUB) {
+        err = "more than 64 nonlinear sub-problems";
+        return false;
+    }
+    H.nx = m.nx; H.nu = m.nu; H.ny = m.ny; H.nsub = (int)m.subs.size();
+    int o = 0, rows = 0;
+    auto take = [&](int n) { int at = o; o += n; return at; };
+    int nnt = 0, npt = 0;
+    for (const HostSub &s : m.subs) { nnt += s.nn; npt += s.np; }
+    H.nnt = nnt; H.npt = npt;
+    H.o_a = take(m.nx * m.nx); H.o_b = take(m.nx * m.nu); H.o_c = take(m.nx * nnt); H.o_x0 = take(m.nx);
+    H.o_dy = take(m.ny * m.nx); H.o_ey = take(m.ny * m.nu); H.o_fy = take(m.ny * nnt); H.o_y0 = take(m.ny);
+    int zoff = 0, poff = 0, coff = 0;
+    for (int k = 0; k < H.nsub; ++k) {
+        const HostSub &s = m.subs[k];
+        GenSub &g = H.sub[k];
+        g.nn = s.nn; g.nq = s.nq; g.np = s.np; g.zoff = zoff; g.poff = poff;
+        g.o_pexp = take(s.nq * s.np); g.o_dq = take(s.np * m.nx); g.o_eq = take(s.np * m.nu);
+        g.o_fqprev = take(s.np * nnt); g.o_fq = take(s.nq * s.nn); g.o_q0 = take(s.nq);
+        g.row0 = rows;
+        g.c_off = coff;
+        rows += s.nn;
+        zoff += s.nn; poff += s.np;
+        coff += (s.np + s.nn) * CACHE + 2;
+        if (s.nn > H.nnmax) H.nnmax = s.nn;
+        if (s.nq > H.nqmax) H.nqmax = s.nq;
+        if (s.np > H.npmax) H.npmax = s.np;
+    }
+    H.image_total = o > 0 ? o : 1;
+    H.cache_total = coff > 0 ? coff : 1;
+    H.state_total = m.nx + npt + nnt;
+    G.image.assign(H.image_total, 0.0);
+    auto putm = [&](int at, const std::vector<double> &v) { for (size_t i = 0; i < v.size(); ++i) G.image[at + i] = v[i]; };
+    putm(H.o_a, m.a); putm(H.o_b, m.b); putm(H.o_c, m.c); putm(H.o_x0, m.x0);
+    putm(H.o_dy, m.dy); putm(H.o_ey, m.ey); putm(H.o_fy, m.fy); putm(H.o_y0, m.y0);
+    const int blocks = (rows + GROUP - 1) / GROUP;
+    G.rowc.assign((size_t)(blocks > 0 ? blocks : 1) * ROWC * GROUP, 0.0);
+    G.rowi.assign((size_t)(blocks > 0 ? blocks : 1) * ROWI * GROUP, 0);
+    G.init_state.assign(H.state_total > 0 ? H.state_total : 1, 0.0);
+    Packed dummy;       // (describe_element notes has_bjt / rare kinds there)
+    for (int k = 0; k < H.nsub; ++k) {
+        const HostSub &s = m.subs[k];
+        const GenSub &g = H.sub[k];
+        putm(g.o_pexp, s.pexp); putm(g.o_dq, s.dq); putm(g.o_eq, s.eq); putm(g.o_fqprev, s.fqprev);
+        putm(g.o_fq, s.fq); putm(g.o_q0, s.q0);
+        for (int i = 0; i < s.nn; ++i) G.init_state[m.nx + npt + g.zoff + i] = s.init_z[i];
+        std::vector<char> have(s.nn, 0);
+        for (size_t e = 0; e < s.kind.size(); ++e) {
+            int knq, knn;
+            kind_shape(s.kind[e], knq, knn);
+            for (int er = 0; er < knn; ++er) {
+                const int row = s.roff[e] + er;
+                if (row < 0 || row >= s.nn || s.qoff[e] < 0 || s.qoff[e] + knq > s.nq) { err = "element table out of range"; return false; }
+                double rc[ROWC];
+                int ri[ROWI];
+                if (!describe_element(s.kind[e], &s.par[e * MAX_ELEM_PAR], er, s.qoff[e], rc, ri, dummy, err)) return false;
+                const int R = g.row0 + row, blk = R / GROUP, ln = R % GROUP;
+                for (int c = 0; c < ROWC; ++c) G.rowc[((size_t)blk * ROWC + c) * GROUP + ln] = rc[c];
+                for (int w = 0; w < ROWI; ++w) G.rowi[((size_t)blk * ROWI + w) * GROUP + ln] = ri[w];
+                have[row] = 1;
+            }
+        }
+        for (int r = 0; r < s.nn; ++r)
+            if (!have[r]) { err = "a residual row belongs to no element"; return false; }
+    }
+    H.has_bjt = dummy.has_bjt;
+    // workspace
+    int w = 0;
+    auto wt = [&](int n) { int at = w; w += n; return at; };
+    H.w_x = wt(m.nx); H.w_xn = wt(m.nx); H.w_z = wt(nnt);
+    for (int k = 0; k < H.nsub; ++k) {
+        GenSub &g = H.sub[k];
+        g.w_lp = wt(g.np); g.w_lz = wt(g.nn); g.w_ljp = wt(g.nn * g.np); g.w_llu = wt(g.nn * g.nn); g.w_lpiv = wt(g.nn);
+    }
+    H.w_p = wt(H.npmax); H.w_pa = wt(H.npmax); H.w_sp = wt(H.npmax); H.w_zz = wt(H.nnmax); H.w_res = wt(H.nnmax);
+    H.w_dz = wt(H.nnmax); H.w_lu = wt(H.nnmax * H.nnmax); H.w_piv = wt(H.nnmax); H.w_jp = wt(H.nnmax * H.npmax);
+    H.w_q = wt(H.nqmax); H.w_pf = wt(H.nqmax); H.w_tv = wt(4 * H.nnmax); H.w_tmp = wt(H.nnmax);
+    H.ws_total = w > 0 ? w : 1;
     return true;
 }
 

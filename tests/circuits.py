@@ -166,3 +166,27 @@ def clipper_chain(stages):
         prev = (r, 2)
     spec.append(("j_out", voltageprobe(), {"-": "gnd", "+": prev}))
     return build(spec)
+
+
+def buffered_clipper_chain(stages, bias=0.0):
+    """`stages` diode-clipper stages separated by ideal op-amp buffers (two_stage_clipper, continued): the
+    nonlinearity decomposes into one sub-problem per stage, each fed by the one before through its buffer -- models
+    with any number of nonlinear sub-problems."""
+    from acme_jl_amd.circuit import capacitor, diode, opamp, resistor, voltageprobe, voltagesource
+    from acme_jl_amd.examples import build
+    spec = [("j_in", voltagesource(), {"-": "gnd"}),
+            ("j_b", voltagesource(bias), {"-": ("j_in", "+")})]
+    prev = ("j_b", "+")
+    for k in range(stages):
+        r, c, d1, d2, buf = f"r{k}", f"c{k}", f"da{k}", f"db{k}", f"buf{k}"
+        spec += [(r, resistor(1e3 * (1 + 0.4 * k)), {1: prev}),
+                 (c, capacitor(47e-9 / (1 + 0.3 * k)), {1: (r, 2), 2: "gnd"}),
+                 (d1, diode(is_=1e-15 * (1 + k), eta=1 + 0.1 * k), {"-": "gnd", "+": (r, 2)}),
+                 (d2, diode(is_=1.8e-15 * (1 + k), eta=1 + 0.1 * k), {"-": (r, 2), "+": "gnd"})]
+        if k + 1 < stages:
+            spec.append((buf, opamp(), {"in+": (r, 2), "in-": f"bo{k}", "out+": f"bo{k}", "out-": "gnd"}))
+            prev = f"bo{k}"
+        else:
+            prev = (r, 2)
+    spec.append(("j_out", voltageprobe(), {"-": "gnd", "+": prev}))
+    return build(spec)

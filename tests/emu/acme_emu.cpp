@@ -236,6 +236,11 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return 0;
 }
+// the generic kernel has no cross-lane operation: its "lanes" run one after the other
+static inline int launch_generic(const GArgs &A, stream_t) {
+    for (long long i = 0; i < A.n_inst; ++i) gen_main(A, i);
+    return 0;
+}
 // the fiber scheduler below is not re-entrant: asynchronous runs (acme_batch_run_async) take turns
 static inline std::mutex *run_mutex() { static std::mutex m; return &m; }
 }  // namespace be

@@ -165,3 +165,18 @@ def moving_pot_inputs(N, T, seed=5):
             u[i, 1 + k] = pot
     u[0] = np.stack([sine(T), np.linspace(1, 0, T), np.linspace(0, 1, T), np.linspace(1, 0, T)])
     return u
+
+
+def beyond_the_tuned_shapes():
+    """(name, model, u[N, nu, T]) for models no tuned kernel shape holds -- 20 unknowns in one sub-problem, six
+    nonlinear sub-problems, 40 states: the generic lane-per-instance kernel (acme_generic.h) takes them."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import DiscreteModel
+    t = Fraction(1, FS)
+    amp = np.array([0.2, 1.0, 3.0])
+    u = amp[:, None, None] * sine(200)[None, None, :]
+    return [("20 unknowns", DiscreteModel(circuits.clipper_chain(10), t, HS, decompose_nonlinearity=False), u),
+            ("6 sub-problems", DiscreteModel(circuits.buffered_clipper_chain(6), t, HS), u),
+            ("40-stage RC ladder", DiscreteModel(examples.rc_ladder(40), t, HS), u)]

@@ -654,3 +654,46 @@ def test_emulated_progress_callback_and_host_buffer_release(emu_lib):
     assert seen == [(100, 100)]
     r.release_host_buffers()
     r.release_host_buffers()                   # idempotent
+
+
+def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):
+    """Models beyond every tuned kernel shape (20 unknowns, 6 sub-problems, 40 states) run in the generic
+    lane-per-instance kernel and walk the oracle's path (identical iteration totals, outputs to rounding), on both
+    solver stacks and across a launch boundary; the same kernel, forced onto the BASELINE models (ACME_GENERIC=1),
+    agrees with the oracle as well, and its solve / Jacobian / state entry points with the tuned kernels'."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes
+    for name, m, u in beyond_the_tuned_shapes():
+        assert max([s.nn for s in m.subs] + [0]) > 16 or len(m.subs) > 4 or m.nx > 32, name
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m.solver = solver
+            r = emu_runner(emu_lib, m, u.shape[0])
+            y = np.concatenate([r.run(u[:, :, :70]), r.run(u[:, :, 70:])], axis=2)
+            yref, its = oracle_run(m, u, cache_limit=lim)
+            assert_close(y, yref, rtol=RTOL_SAME)
+            assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
+    monkeypatch.setenv("ACME_GENERIC", "1")
+    for name, N, T in (("diodeclipper", 3, 150), ("superover_var", 2, 100)):
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m = load(name, solver)
+            u = sweep_inputs(name, N, T)
+            r = emu_runner(emu_lib, m, N)
+            yref, its = oracle_run(m, u, cache_limit=lim)
+            assert_close(r.run(u), yref, rtol=RTOL_SAME)
+            assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
+    m = load("superover_fixed", HS)
+    u = sweep_inputs("superover_fixed", 3, 80)
+    got = {}
+    for gen in ("1", "0"):
+        monkeypatch.setenv("ACME_GENERIC", gen)
+        r = emu_runner(emu_lib, m, 3)
+        r.run(u)
+        x, p, z = r.get_state()
+        jac = r.get_extrapolation_jacobian()
+        zs, conv, its = r.solve(p * (1 + 1e-9))
+        r.set_state(x=x, p=p, z=z)
+        y2 = r.run(u[:, :, :20])
+        got[gen] = (x, p, z, jac, zs, conv, its, y2)
+    for a, b in zip(got["1"], got["0"]):
+        b = np.asarray(b, dtype=float)
+        np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=1e-9, atol=1e-12 + 1e-12 * np.abs(b).max())

@@ -717,3 +717,34 @@ def test_host_buffer_paths_agree_bit_for_bit(hip_lib, monkeypatch):
             assert np.array_equal(a, b), mode
     yref, _ = oracle_run(m, u[:4])
     assert_close(np.transpose(yd[:4], (0, 2, 1)), yref)
+
+
+@pytest.mark.gpu
+def test_generic_kernel_never_refuses(hip_lib, monkeypatch):
+    """Models no tuned kernel shape holds -- 20 unknowns in one sub-problem, six nonlinear sub-problems, a 40-state
+    ladder -- run in the generic lane-per-instance kernel and follow the oracle (RTOL_SAME, identical iteration
+    totals), on both solver stacks, across a launch boundary, with 200 instances; forced onto a BASELINE model
+    (ACME_GENERIC=1) it agrees with the oracle too."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes
+    for name, m, u3 in beyond_the_tuned_shapes():
+        N, T = 200, u3.shape[2]
+        amp = np.logspace(-1, 0.5, N)
+        u = amp[:, None, None] * sine(T)[None, None, :]
+        spot = [0, 57, 123, 199]
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m.solver = solver
+            r = ModelRunner(m, N, lib=hip_lib)
+            y = np.concatenate([r.run(u[:, :, :70]), r.run(u[:, :, 70:])], axis=2)
+            yref, its = oracle_run(m, u[spot], cache_limit=lim)
+            err = assert_close(y[spot], yref, rtol=RTOL_SAME)
+            got = r.report_arrays()["iters_total"][spot]
+            print(f"generic kernel, {name}, {solver}: shape {r.kernel_shape()}, rel err {err:.2e}, iterations {got.tolist()} vs {its.tolist()}")
+            assert got.tolist() == its.tolist()
+    monkeypatch.setenv("ACME_GENERIC", "1")
+    m = load("superover_var", CachingHomotopySolver)
+    u = sweep_inputs("superover_var", 64, 300)
+    r = ModelRunner(m, 64, lib=hip_lib)
+    yref, its = oracle_run(m, u[:6], cache_limit=16)
+    assert_close(r.run(u)[:6], yref)

@@ -24,8 +24,14 @@ cases = [
     ("clipper chain, 2 stages (nn 4)", DiscreteModel(circuits.clipper_chain(2), t, CachingHomotopySolver, decompose_nonlinearity=False)),
     ("clipper chain, 4 stages (nn 8)", DiscreteModel(circuits.clipper_chain(4), t, CachingHomotopySolver, decompose_nonlinearity=False)),
     ("clipper chain, 8 stages (nn 16)", DiscreteModel(circuits.clipper_chain(8), t, CachingHomotopySolver, decompose_nonlinearity=False)),
-    ("clipper chain, 4 stages, decomposed (nsub 4)", DiscreteModel(circuits.clipper_chain(4), t, CachingHomotopySolver)),
+    # (stages separated by op-amp buffers: one sub-problem per stage -- the directly coupled chain above does not decompose)
+    ("buffered clipper chain, 4 stages (nsub 4)", DiscreteModel(circuits.buffered_clipper_chain(4), t, CachingHomotopySolver)),
+    # beyond the tuned shapes: the generic lane-per-instance kernel (acme_generic.h)
+    ("clipper chain, 10 stages (nn 20) [generic]", DiscreteModel(circuits.clipper_chain(10), t, CachingHomotopySolver, decompose_nonlinearity=False)),
+    ("buffered clipper chain, 6 stages (nsub 6) [generic]", DiscreteModel(circuits.buffered_clipper_chain(6), t, CachingHomotopySolver)),
 ]
+if len(sys.argv) > 3:      # a subset by substring
+    cases = [c for c in cases if sys.argv[3] in c[0]]
 dev = torch.device("cuda", 0)
 sig = torch.sin(2 * np.pi * 1000 / 44100 * torch.arange(T, dtype=torch.float64, device=dev))
 amp = torch.logspace(-2, 0.7, N, dtype=torch.float64, device=dev)
