@@ -220,6 +220,10 @@ struct KArgs {
     // condensed shapes (Dims::nl > 0) keep z in a PERMUTED basis (the linear rows' pivot columns first, acme_pack.h):
     // zperm[i] = the caller's index of the kernel's z_i (identity otherwise); z_out / jac_out are written through it
     int zperm[GROUP];
+    // A launch over a SUBSET of the batch's instances (isolation of slow instances, acme_batch_set_isolation): n_inst
+    // is then the number of instances of the launch and inst_map[slot] the batch instance slot `slot` works on
+    // (nullptr: slot i is instance i)
+    const int *inst_map;
     int *cflags;             // [n_inst]: bit 0 = the extrapolation origin may lie OFF the linear rows' subspace
                              // (initial solution, acme_batch_set_state, an iterate accepted without a Newton step)
 };

@@ -117,6 +117,7 @@ static inline int host_register(void *p, size_t n) { return (int)hipHostRegister
 static inline int host_unregister(void *p) { return (int)hipHostUnregister(p); }
 static inline int host_device_pointer(void **d, void *h) { return (int)hipHostGetDevicePointer(d, h, 0); }
 static inline int stream_create_nonblocking(stream_t *st) { return (int)hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
+static inline bool stream_idle(stream_t st) { return hipStreamQuery(st) == hipSuccess; }
 static inline int stream_destroy(stream_t st) { return st ? (int)hipStreamDestroy(st) : 0; }
 static inline int device_sync() { return (int)hipDeviceSynchronize(); }
 static inline int stream_sync(stream_t st) { return (int)hipStreamSynchronize(st); }

@@ -786,9 +786,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     const int lane = tid & 63, wave = tid >> 6;
     const int lig = lane & (GROUP - 1), grp = lane >> 4;
     const int gib = wave * GROUPS_PER_WAVE + grp;  // group in block
-    const long long inst = (long long)wv::bid() * INST_PER_BLOCK + gib;
+    const long long slot = (long long)wv::bid() * INST_PER_BLOCK + gib;
     const bool per_inst = A.image_stride != 0;
-    const bool valid = inst < A.n_inst;
+    const bool valid = slot < A.n_inst;
+    // (a launch over a subset of the batch: KArgs::inst_map)
+    const long long inst = (A.inst_map && valid) ? (long long)A.inst_map[slot] : slot;
 
     // ---- LDS carve-up -------------------------------------------------------------------
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));   // the block's dynamic LDS starts at 0
@@ -819,6 +821,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             for (int g = 0; g < INST_PER_BLOCK; ++g) {
                 long long ii = (long long)wv::bid() * INST_PER_BLOCK + g;
                 if (ii >= A.n_inst) ii = A.n_inst - 1;
+                if (A.inst_map) ii = A.inst_map[ii];
                 const double *src = A.image + ii * A.image_stride;
                 for (int i = tid; i < S::IMGN; i += nthreads) lds_img[g * S::IMGN + i] = src[S::IMG0 + i];
             }
@@ -1000,7 +1003,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             constexpr int t = decltype(tc_)::value;
             double acc = q0_in_pad ? pe[t][NP] : q0v[t];
             if constexpr (S::FUSE) {       // one statement per term; the first one waits for p (DPP hazard)
-                wv::fmac_bcast_chain<NP, t == 0 || S::CHAINWAIT>(acc, p, pe[t]);
+                wv::fmac_bcast_chain<NP, true>(acc, p, pe[t]);
             } else {
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
@@ -1066,7 +1069,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA { e[decltype(tc_)::value] = pf[decltype(tc_)::value]; });
             sfor<0, NT>([&](auto tc_) ACME_LAMBDA {      // one statement per term; the first one waits for zz
                 constexpr int t = decltype(tc_)::value;
-                wv::fmac_bcast_chain<NN, t == 0 || S::CHAINWAIT>(e[t], zz, fqv[t]);
+                wv::fmac_bcast_chain<NN, true>(e[t], zz, fqv[t]);      // (every statement waits: the compiler may copy zz between them)
             });
         }
         ACME_T2(TB_E1);
@@ -1737,11 +1740,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA { cpv[decltype(jc)::value] = cp[decltype(jc)::value * CACHE + (lig & (CACHE - 1))]; });
                 wv::sched_fence();
                 const double m1 = wv::keep(-1.0);
-                wv::dpp_wait();
+                const double tg = wv::settle(target);      // (two wait states old whatever the compiler did to `target` just before)
                 sfor<0, NP>([&](auto jc) ACME_LAMBDA {
                     constexpr int j = decltype(jc)::value;
                     double t = cpv[j];
-                    wv::fmac_bcast<j>(t, target, m1);
+                    wv::fmac_bcast<j>(t, tg, m1);
                     d = fma(t, t, d);
                 });
             }

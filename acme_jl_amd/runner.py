@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
-    "acme_batch_run_async", "acme_batch_wait", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback",
+    "acme_batch_run_async", "acme_batch_wait", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
@@ -117,6 +117,7 @@ class Library:
         L.acme_batch_run_async.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_wait.argtypes = [vp]
         L.acme_batch_release_host_buffers.argtypes = [vp]
+        L.acme_batch_set_isolation.argtypes = [vp, C.c_double]
         L.acme_batch_set_progress_callback.argtypes = [vp, PROGRESS_FN, vp]
         L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_get_extrapolation_jacobian.argtypes = [vp, C.c_int, dp, C.c_int, vp]
@@ -236,6 +237,12 @@ class ModelRunner:
             self.lib.check(self.lib.L.acme_batch_set_progress_callback(self.h, self._progress_cb, None))
         if models is not None:
             self.set_models(0, models)
+
+    def set_isolation(self, iters_per_sample):
+        """Run the instances that needed more than ``iters_per_sample`` Newton iterations per sample over the previous
+        run in a launch of their own (``acme_batch_set_isolation``): device-pointer runs then complete on the caller's
+        stream for the others, ``wait()`` completes the slow ones.  0 switches it off."""
+        self.lib.check(self.lib.L.acme_batch_set_isolation(self.h, float(iters_per_sample)))
 
     def release_host_buffers(self):
         """Un-page-lock the arrays of the last host-buffer run (``acme_batch_release_host_buffers``)."""

@@ -168,6 +168,20 @@ int acme_batch_run_async(acme_batch *b, const double *u, double *y, long long T,
                          void *stream);
 int acme_batch_wait(acme_batch *b);
 
+/* Isolation of slow instances.  A launch lasts as long as its slowest wave, and every wave is one serial recurrence
+ * over the samples: ONE pathological cell of a sweep -- say a potentiometer at an end stop that makes the model
+ * singular, where the solver stack fails after ~900 Newton iterations per sample while every other cell needs 3 --
+ * holds the results of all instances back by its own, hundreds of times longer, run.  With a threshold > 0 the
+ * instances that needed more than `iters_per_sample` Newton iterations per sample over the batch's previous run are
+ * launched on their own, on a stream of the library's; the others run on the caller's stream as if the slow ones were
+ * not there.  What an instance computes does not depend on the group it runs in (bit-identical results).  A
+ * device-pointer run (ACME_MEM_DEVICE) then completes on the caller's stream for the FAST instances only;
+ * acme_batch_wait (or any entry point that reads the batch) completes the slow ones.  Host-buffer runs return
+ * complete, as ever.  The first run of a batch is never split (nothing is known yet); groups are re-formed between
+ * runs while no launch of the slow group is in flight.  0 switches the isolation off (default).  Not for batches the
+ * lane-per-instance or generic kernels run. */
+int acme_batch_set_isolation(acme_batch *b, double iters_per_sample);
+
 /* The solver plugin contract, batched (src/solvers.jl:207-236, 268-302): for every instance
  *   z = solve(solver, p); converged = hasconverged(solver); iters = needediterations(solver)
  * on sub-problem `sub` (0-based): p is [N][np_sub], z is [N][nn_sub], converged/iters are [N].  Like the reference's

@@ -34,7 +34,7 @@ import ProgressMeter
 import ACME: run!, solve, hasconverged, needediterations, set_resabstol!,
              get_extrapolation_origin, set_extrapolation_origin, get_extrapolation_jacobian
 
-export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, release_host_buffers!
+export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, release_host_buffers!, set_isolation!
 
 const lib = get(ENV, "ACME_HIP_LIB", "libacme_hip.so")
 
@@ -240,6 +240,16 @@ freeing or resizing them while the runner lives on.
 """
 release_host_buffers!(r::BatchRunner) =
     (check(ccall((:acme_batch_release_host_buffers, lib), Cint, (Ptr{Cvoid},), r.h)); r)
+
+"""
+    set_isolation!(runner, iters_per_sample)
+
+Launch the instances that needed more than `iters_per_sample` Newton iterations per sample over the previous run on
+their own (a pathological cell of a sweep otherwise holds every other instance's results back by its own, hundreds of
+times longer, run; `include/acme_hip.h`).  `0` switches it off.
+"""
+set_isolation!(r::BatchRunner, iters_per_sample::Real) =
+    (check(ccall((:acme_batch_set_isolation, lib), Cint, (Ptr{Cvoid}, Cdouble), r.h, iters_per_sample)); r)
 
 """
     set_models!(runner, first, models)

@@ -225,6 +225,7 @@ static inline int host_register(void *, size_t) { ++g_registered; return 0; }
 static inline int host_unregister(void *) { --g_registered; return 0; }
 static inline int host_device_pointer(void **d, void *h) { *d = h; return 0; }
 static inline int stream_create_nonblocking(stream_t *st) { *st = nullptr; return 0; }
+static inline bool stream_idle(stream_t) { return true; }
 static inline int stream_destroy(stream_t) { return 0; }
 static inline int device_sync() { return 0; }
 static inline int stream_sync(stream_t) { return 0; }

@@ -697,3 +697,33 @@ def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):
     for a, b in zip(got["1"], got["0"]):
         b = np.asarray(b, dtype=float)
         np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=1e-9, atol=1e-12 + 1e-12 * np.abs(b).max())
+
+
+def test_emulated_isolation_of_slow_instances(emu_lib):
+    """acme_batch_set_isolation: the instances that needed more than a threshold of iterations per sample over the
+    previous run get a launch of their own (KArgs::inst_map), the others theirs -- and nothing anybody computes
+    changes, bit for bit; groups are re-formed run after run.  (Threshold set to the sweep's median here, so that the
+    batch really splits; the GPU test runs the singular drive = 1.0 cells this is meant for.)"""
+    from helpers import HS
+    m = load("superover_var", HS)
+    N, T = 9, 60
+    u = sweep_inputs("superover_var", N, T, seed=11)
+    ref = emu_runner(emu_lib, m, N)
+    y_ref = [ref.run(u) for _ in range(3)]
+    per = ref.report_arrays()["iters_total"] / (3 * T)
+    thr = float(np.median(per))
+    assert per.min() < thr < per.max()
+    r = emu_runner(emu_lib, m, N)
+    r.set_isolation(thr)
+    y = [r.run(u) for _ in range(3)]      # run 1: one launch (nothing known yet); runs 2 and 3: two groups
+    for a, b in zip(y, y_ref):
+        assert np.array_equal(a, b)
+    ra, rb = r.report_arrays(), ref.report_arrays()
+    for k in ("iters_total", "n_warn", "iters_max", "first_nonconverged"):
+        assert np.array_equal(ra[k], rb[k]), k
+    for a, b in zip(r.get_state(), ref.get_state()):
+        assert np.array_equal(a, b)
+    z, conv, its = r.solve(r.get_state()[1])          # (entry points that read the batch see it complete)
+    assert conv.all()
+    r.set_isolation(0.0)
+    assert np.array_equal(r.run(u), ref.run(u))

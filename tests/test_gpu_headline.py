@@ -254,3 +254,72 @@ def test_condensed_kernel_moving_pots_many_instances(hip_lib, monkeypatch):
             assert abs(float(ra["iters_total"].sum()) - its.sum()) <= 0.01 * its.sum()
             assert dev.max() <= (0.0 if lim is None else 0.10)
             assert (ra["first_nonfinite"] < 0).all() and ra["n_warn"].sum() <= warn.sum() + 1
+
+
+def test_pathological_tail_literal_grid(hip_lib):
+    """SURVEY 8(d)'s LITERAL config-3 grid -- drive in linspace(0, 1, 32): its last column, 256 of the 8 192 instances,
+    sits on the singular drive = 1.0 corner, where the reference's solver stack fails on practically every sample after
+    ~900 Newton iterations (a launch lasts as long as its slowest wave: ~300 x longer than without the column).
+    * the singular cells follow the oracle: warning counts equal, outputs at RTOL;
+    * what the 7 936 healthy instances compute does not depend on the singular ones being in the batch (bit-identical
+      to a run without them);
+    * with acme_batch_set_isolation the healthy instances' results are complete on the caller's stream in a fraction of
+      the time the slow ones need -- and nothing anybody computes changes."""
+    import time
+    import torch
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import RTOL
+    N, T = 8192, 1500
+    dev = torch.device("cuda", 0)
+    m = load("superover_var", CachingHomotopySolver)
+    idx = np.arange(N)
+    pots = np.stack([(idx // 256) / 31.0, ((idx // 16) % 16) / 15.0, (idx % 16) / 15.0], axis=1)
+    healthy = pots[:, 0] < 1.0
+    un = np.zeros((N, T, 4))
+    un[:, :, 0] = sine(T)[None, :]
+    un[:, :, 1:] = pots[:, None, :]
+    u = torch.from_numpy(un).to(dev)
+
+    def timed_runs(r, uu, nruns):
+        out = []
+        for _ in range(nruns):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            y = r.run_torch(uu)
+            torch.cuda.current_stream().synchronize()      # the caller's stream
+            t_stream = time.perf_counter() - t0
+            r.wait(check=False)                             # ... and (isolation) the library's
+            torch.cuda.synchronize()
+            out.append((y.clone(), t_stream, time.perf_counter() - t0))
+        return out
+    plain = ModelRunner(m, N, lib=hip_lib)
+    p = timed_runs(plain, u, 2)
+    alone = ModelRunner(m, int(healthy.sum()), lib=hip_lib)
+    a = timed_runs(alone, u[torch.from_numpy(healthy).to(dev)].contiguous(), 2)
+    iso = ModelRunner(m, N, lib=hip_lib)
+    iso.set_isolation(50.0)
+    s = timed_runs(iso, u, 2)
+    hmask = torch.from_numpy(healthy).to(dev)
+    for k in range(2):
+        assert torch.equal(p[k][0][hmask], a[k][0]), "healthy instances depend on their neighbours"
+        assert torch.equal(p[k][0], s[k][0]), "isolation changed a result"
+    rp, rs = plain.report_arrays(), iso.report_arrays()
+    for key in ("iters_total", "n_warn", "first_nonconverged", "iters_max"):
+        assert np.array_equal(rp[key], rs[key]), key
+    per = rp["iters_total"] / (2.0 * T)
+    print(f"literal grid, {T} samples: all instances in one launch {1e3 * p[1][2]:.0f} ms; healthy ones alone {1e3 * a[1][2]:.0f} ms; "
+          f"with isolation: healthy complete after {1e3 * s[1][1]:.0f} ms, all after {1e3 * s[1][2]:.0f} ms; iterations/sample healthy "
+          f"{per[healthy].mean():.2f}, singular {per[~healthy].mean():.0f}; warnings {int(rp['n_warn'][~healthy].sum())} "
+          f"(healthy: {int(rp['n_warn'][healthy].sum())})")
+    assert per[~healthy].min() > 100 and per[healthy].max() < 60
+    # second run, groups formed: the healthy instances lose at most 10 % against a batch without the singular column
+    assert s[1][1] <= 1.10 * a[1][2] + 2e-3, (s[1][1], a[1][2])
+    assert s[1][1] < 0.2 * p[1][2]
+    spot = [31 * 256, 31 * 256 + 77, 8191, 1000, 5000]
+    yref, its, warn = oracle_parallel("superover_var", CachingHomotopySolver, np.transpose(un[spot], (0, 2, 1)), cache_limit=16)
+    y_first = np.transpose(p[0][0][spot].cpu().numpy(), (0, 2, 1))
+    assert rel_err(y_first, yref) <= RTOL
+    first = ModelRunner(m, len(spot), lib=hip_lib)
+    first.run(np.transpose(un[spot], (0, 2, 1)), check=False)
+    assert first.report_arrays()["n_warn"].tolist() == warn.tolist()
