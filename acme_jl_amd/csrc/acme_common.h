@@ -224,6 +224,9 @@ struct KArgs {
     // is then the number of instances of the launch and inst_map[slot] the batch instance slot `slot` works on
     // (nullptr: slot i is instance i)
     const int *inst_map;
+    // lane-per-instance kernel: instances per wave (1 .. 64; the lanes beyond idle).  A batch that leaves SIMDs empty
+    // is spread thinner: a wave's Newton loop runs as long as its slowest lane needs, and fewer lanes have a smaller maximum
+    int lane_density;
     int *cflags;             // [n_inst]: bit 0 = the extrapolation origin may lie OFF the linear rows' subspace
                              // (initial solution, acme_batch_set_state, an iterate accepted without a Newton step)
 };

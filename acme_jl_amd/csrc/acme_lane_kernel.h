@@ -120,8 +120,9 @@ template <class S> ACME_DEV void lane_main(const KArgs &A, double *lds) {
     static_assert(LaneShape<S>::supported, "shape not supported by the lane-per-instance kernel");
 
     const int lane = wv::tid();                 // lane within the block
-    const long long inst = (long long)wv::bid() * LANE_BLOCK + lane;
-    const bool valid = inst < A.n_inst;
+    const int dens = A.lane_density > 0 && A.lane_density < 64 ? A.lane_density : 64;
+    const long long inst = ((long long)wv::bid() * WAVES_PER_BLOCK + (lane >> 6)) * dens + (lane & 63);
+    const bool valid = (lane & 63) < dens && inst < A.n_inst;
     const long long ii = valid ? inst : 0;
     // The model's constants (LaneLayout block: everything a row needs is contiguous): read-only for the
     // whole launch and addressed uniformly by the wave, so they are FETCHED by scalar loads

@@ -50,7 +50,9 @@ extern "C" {
 #define ACME_KIND_BJT 2    /* ise,isc,etae,etac,bf,br,ile,ilc,etael,etacl,vaf,var,ikf,ikr
                                                                        src/elements.jl:309-406 */
 #define ACME_KIND_POT 3    /* r                                         src/elements.jl:20-31   */
-#define ACME_KIND_MOSFET 4 /* polarity,lambda,nvt,vt[4],nalpha,alpha[4] src/elements.jl:436-481 */
+#define ACME_KIND_MOSFET 4 /* polarity,lambda,nvt,vt[4],nalpha,alpha[4] src/elements.jl:436-481
+                              (the reference takes polynomials of any length, :436-450; here 1 ... 4 coefficients
+                              each: acme_model_add_subproblem returns ACME_ERR_UNSUPPORTED beyond that) */
 #define ACME_KIND_MACAK 5  /* gain, scale                               src/elements.jl:536-551 */
 #define ACME_KIND_JA 6     /* Ms,a,alpha,c,k                            src/elements.jl:100-135 */
 #define ACME_MAX_ELEM_PAR 16

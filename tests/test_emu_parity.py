@@ -727,3 +727,24 @@ def test_emulated_isolation_of_slow_instances(emu_lib):
     assert conv.all()
     r.set_isolation(0.0)
     assert np.array_equal(r.run(u), ref.run(u))
+
+
+def test_emulated_mosfet_polynomial_cap_is_reported_by_the_abi(emu_lib):
+    """The reference's MOSFET takes threshold / gain polynomials of any length (src/elements.jl:436-450); the element
+    table holds 4 coefficients each -- more is refused by acme_model_add_subproblem itself, with a message."""
+    import ctypes as C
+    L = emu_lib.L
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    mh = C.c_void_p()
+    z = (C.c_double * 1)(0.0)
+    emu_lib.check(L.acme_model_create(0, 0, 0, 1, z, z, z, z, z, z, z, z, C.byref(mh)))
+    par = np.zeros(16)
+    par[:12] = [1.0, 0.0, 5.0, 0.1, 0.2, 0.3, 0.4, 1.0, 2.0, 0.0, 0.0, 0.0]      # nvt = 5
+    one = np.ones(3)
+    kind, qoff, roff = (np.array([v], dtype=np.int32) for v in (4, 0, 0))
+    rc = L.acme_model_add_subproblem(mh, 1, 3, 1, one.ctypes.data_as(dp), one.ctypes.data_as(dp), one.ctypes.data_as(dp),
+                                     one.ctypes.data_as(dp), one.ctypes.data_as(dp), one.ctypes.data_as(dp),
+                                     one.ctypes.data_as(dp), 1, kind.ctypes.data_as(ip), qoff.ctypes.data_as(ip),
+                                     roff.ctypes.data_as(ip), par.ctypes.data_as(dp))
+    assert rc < 0 and b"1 ... 4 coefficients" in L.acme_last_error()
+    L.acme_model_destroy(mh)
