@@ -1772,7 +1772,6 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             bool mv = false, mvpre = false, back = false;
             int ph = wv::opaque(1);
             for (;;) {
-                if (ph != 0) LU::template load_stored_n<NR, S>(cmul, ojp);       // requested first: needed last
                 set_p(wv::settle(ph != 0 ? target : lp));
                 if (ph != 0 && !back) {
                     // an origin to (re-)linearise, or potentiometers that moved since the origin was taken (opos is not
@@ -1850,6 +1849,9 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 }
                 ph = wv::opaque(1);
             }
+            // (the origin's recorded multipliers, requested only now: held across the phase loop they cost 16 registers
+            // there -- 170 more spilled values in the rare paths -- for latency the other wave covers anyway)
+            LU::template load_stored_n<NR, S>(cmul, ojp);
             c = base_solve_c(target, need, its, cmul, mv, z0m);
         } else {
             if (ACME_RARE(wv::ballot(reorig))) {

@@ -52,7 +52,7 @@ class Report(C.Structure):
 ABI_SYMBOLS = [
     "acme_last_error", "acme_device_count", "acme_default_options", "acme_model_create",
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
-    "acme_model_kernel_shape",
+    "acme_model_kernel_shape", "acme_model_kernel_variant",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
     "acme_batch_run_async", "acme_batch_wait", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
@@ -109,6 +109,7 @@ class Library:
         L.acme_model_destroy.argtypes = [vp]
         L.acme_model_destroy.restype = None
         L.acme_model_kernel_shape.argtypes = [vp, ip]
+        L.acme_model_kernel_variant.argtypes = [vp, ip, ip]
         L.acme_batch_create.argtypes = [vp, C.c_longlong, C.POINTER(Options), C.POINTER(vp)]
         L.acme_batch_destroy.argtypes = [vp]
         L.acme_batch_destroy.restype = None
@@ -187,6 +188,12 @@ class _ModelHandle:
         dims = (C.c_int * 6)()
         self.lib.check(self.lib.L.acme_model_kernel_shape(self.h, dims))
         return tuple(dims)
+
+    def kernel_variant(self):
+        """(condensed_rows, generic): rows eliminated ahead of the Newton iteration, run-time-sized kernel"""
+        nl, gen = C.c_int(0), C.c_int(0)
+        self.lib.check(self.lib.L.acme_model_kernel_variant(self.h, C.byref(nl), C.byref(gen)))
+        return nl.value, bool(gen.value)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -477,6 +484,9 @@ class ModelRunner:
 
     def kernel_shape(self):
         return self._mh.kernel_shape()
+
+    def kernel_variant(self):
+        return self._mh.kernel_variant()
 
 
 class MultiDeviceRunner:

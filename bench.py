@@ -109,6 +109,15 @@ def pmc_record(workload, n, T):
     return None
 
 
+def kernel_name(runner):
+    """the dominant kernel as the rocprofv3 summaries name it (shape dimensions; condensed rows if any)"""
+    nl, generic = runner.kernel_variant()
+    if generic:
+        return "acme_generic_kernel (run-time dimensions %d,%d,%d,%d,%d,%d)" % runner.kernel_shape()
+    name = "acme_run_kernel<Shape<%d,%d,%d,%d,%d,%d" % runner.kernel_shape()
+    return name + (", condensed rows %d>>" % nl if nl else ">>")
+
+
 def pmc_traffic(workload, n, T):
     """HBM bytes per launch from the PMC passes, or None if no pass for this exact workload is on
     file.  Reads = 2 x FETCH_SIZE: gfx950 tallies this kernel's coalesced reads at half their size
@@ -567,7 +576,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, n_per_gpu, T),
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
-                "kernel": "acme_run_kernel<Shape<%d,%d,%d,%d,%d,%d>>" % runner.kernel_shape(),
+                "kernel": kernel_name(runner),
                 "kernel_ms": last_ms, "algorithmic_bytes_per_launch": abytes,
                 "note": "path is bound by per-wave instruction issue/fetch, not by HBM (DESIGN.md 2); fp64 figure below",
                 "fp64_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T

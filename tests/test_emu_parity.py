@@ -594,6 +594,7 @@ def test_emulated_condensed_kernel_is_selected_and_exact(emu_lib, monkeypatch):
             for cond in ("1", "0"):
                 monkeypatch.setenv("ACME_CONDENSE", cond)
                 r = emu_runner(emu_lib, m, u.shape[0])
+                assert r.kernel_variant() == ((6, False) if cond == "1" else (0, False))
                 y = r.run(u, check=False)
                 assert_close(y, yref, rtol=RTOL_SAME)
                 assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (solver, cond)
@@ -668,6 +669,7 @@ def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):
         for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
             m.solver = solver
             r = emu_runner(emu_lib, m, u.shape[0])
+            assert r.kernel_variant() == (0, True), name
             y = np.concatenate([r.run(u[:, :, :70]), r.run(u[:, :, 70:])], axis=2)
             yref, its = oracle_run(m, u, cache_limit=lim)
             assert_close(y, yref, rtol=RTOL_SAME)
