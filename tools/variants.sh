@@ -14,7 +14,7 @@ if [ "$mode" = build ]; then
     for tu in acme_hip acme_hip_part0 acme_hip_part1 acme_hip_part2 acme_hip_part3; do
       unit=""      # the product's per-unit flags (__graft_entry__.py: HIP_UNIT_FLAGS); NOUNIT=1 builds every unit alike
       case $tu in acme_hip_part[123]) [ -z "$NOUNIT" ] && unit="-mllvm -amdgpu-sched-strategy=${UNITSTRAT:-max-ilp}";; esac
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $unit $flags -c acme_jl_amd/csrc/$tu.hip -o $tmp/$tu.o &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -join-splitedges=1 $unit $flags -c acme_jl_amd/csrc/$tu.hip -o $tmp/$tu.o &
     done
     wait
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $tmp/*.o -o build_variants/libacme_hip_$name.so
