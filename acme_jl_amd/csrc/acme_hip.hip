@@ -75,6 +75,16 @@ __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
     if (i < A.n_inst) gen_main(A, i);
 }
 
+// placement of the waves by their measured cost (acme_balance.h): one thread per wave
+__global__ __launch_bounds__(256) void acme_balance_weight_kernel(BalArgs A) {
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k < A.nw) bal_weight(A, k);
+}
+__global__ __launch_bounds__(256) void acme_balance_place_kernel(BalArgs A) {
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k < A.nw) bal_place(A, k);
+}
+
 static const KernelEntry *find_kernel(const Dims &d) {
     for (const auto &k : kernel_table())
         if (k.d.nn == d.nn && k.d.nq == d.nq && k.d.np == d.np && k.d.nx == d.nx && k.d.nu == d.nu && k.d.ny == d.ny && k.d.rare == d.rare && k.d.nsub == d.nsub && k.d.nl == d.nl)
@@ -129,6 +139,18 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)h
 static inline int launch_generic(const GArgs &A, stream_t st) {
     hipLaunchKernelGGL(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
     return (int)hipGetLastError();
+}
+static inline int launch_balance(const BalArgs &A, stream_t st) {
+    const unsigned g = (unsigned)((A.nw + 255) / 256);
+    hipLaunchKernelGGL(acme_balance_weight_kernel, dim3(g), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(acme_balance_place_kernel, dim3(g), dim3(256), 0, st, A);
+    return (int)hipGetLastError();
+}
+static inline int cu_count(int *n) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipDeviceGetAttribute(n, hipDeviceAttributeMultiprocessorCount, d);
 }
 static inline std::mutex *run_mutex() { return nullptr; }     // HIP: runs of distinct batches are concurrent
 }  // namespace be

@@ -16,6 +16,7 @@
 
 #include "acme_common.h"
 #include "acme_generic.h"
+#include "acme_balance.h"
 #include "acme_shapes.h"
 
 namespace acme {

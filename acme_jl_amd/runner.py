@@ -55,6 +55,7 @@ ABI_SYMBOLS = [
     "acme_model_kernel_shape", "acme_model_kernel_variant",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
     "acme_batch_run_async", "acme_batch_wait", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
+    "acme_batch_set_balance", "acme_batch_get_placement",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
 ]
@@ -119,6 +120,8 @@ class Library:
         L.acme_batch_wait.argtypes = [vp]
         L.acme_batch_release_host_buffers.argtypes = [vp]
         L.acme_batch_set_isolation.argtypes = [vp, C.c_double]
+        L.acme_batch_set_balance.argtypes = [vp, C.c_int]
+        L.acme_batch_get_placement.argtypes = [vp, ip]
         L.acme_batch_set_progress_callback.argtypes = [vp, PROGRESS_FN, vp]
         L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_get_extrapolation_jacobian.argtypes = [vp, C.c_int, dp, C.c_int, vp]
@@ -250,6 +253,18 @@ class ModelRunner:
         run in a launch of their own (``acme_batch_set_isolation``): device-pointer runs then complete on the caller's
         stream for the others, ``wait()`` completes the slow ones.  0 switches it off."""
         self.lib.check(self.lib.L.acme_batch_set_isolation(self.h, float(iters_per_sample)))
+
+    def set_balance(self, mode=-1):
+        """Placement of the waves by their measured cost (``acme_batch_set_balance``): -1 the library decides
+        (default), 0 off, 1 on.  Results do not depend on it (bit-identical)."""
+        self.lib.check(self.lib.L.acme_batch_set_balance(self.h, int(mode)))
+        return self
+
+    def placement(self):
+        """slot -> instance of the next launch (``acme_batch_get_placement``; the identity while nothing is placed)"""
+        out = np.empty(self.n, dtype=np.int32)
+        self.lib.check(self.lib.L.acme_batch_get_placement(self.h, _ip(out)))
+        return out
 
     def release_host_buffers(self):
         """Un-page-lock the arrays of the last host-buffer run (``acme_batch_release_host_buffers``)."""

@@ -188,6 +188,19 @@ int acme_batch_wait(acme_batch *b);
  * lane-per-instance or generic kernels run. */
 int acme_batch_set_isolation(acme_batch *b, double iters_per_sample);
 
+/* Placement of the waves by their measured cost.  Two blocks of a launch share a compute unit and a launch ends with
+ * its slowest SIMD; before a launch (at most once per 4 096 samples) two small kernels on the launch's own stream rank
+ * the waves -- groups of 4 consecutive instances -- by the Newton iterations they needed since the last placement and
+ * deal them to the launch's slots so that heavy and light waves share a SIMD (headline grid: 1.6 % over seconds 1-4 of a
+ * signal, when the cells' costs differ most; nothing in the long steady state; tools/balance_probe.py).  No host synchronisation; what an instance computes does not depend on where it runs
+ * (bit-identical results).  mode: -1 = the library decides (default: on when the launch has more blocks than the
+ * device has compute units), 0 = off, 1 = on.  Not for batches the lane-per-instance or generic kernels run, nor
+ * while acme_batch_set_isolation is in force. */
+int acme_batch_set_balance(acme_batch *b, int mode);
+/* diagnostics: slot_to_instance[N] of the placement the next launch would use (the identity while there is none);
+ * completes the batch's outstanding work first */
+int acme_batch_get_placement(acme_batch *b, int *slot_to_instance);
+
 /* The solver plugin contract, batched (src/solvers.jl:207-236, 268-302): for every instance
  *   z = solve(solver, p); converged = hasconverged(solver); iters = needediterations(solver)
  * on sub-problem `sub` (0-based): p is [N][np_sub], z is [N][nn_sub], converged/iters are [N].  Like the reference's

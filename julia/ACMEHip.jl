@@ -34,7 +34,7 @@ import ProgressMeter
 import ACME: run!, solve, hasconverged, needediterations, set_resabstol!,
              get_extrapolation_origin, set_extrapolation_origin, get_extrapolation_jacobian
 
-export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, release_host_buffers!, set_isolation!
+export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, release_host_buffers!, set_isolation!, set_balance!
 
 const lib = get(ENV, "ACME_HIP_LIB", "libacme_hip.so")
 
@@ -250,6 +250,16 @@ times longer, run; `include/acme_hip.h`).  `0` switches it off.
 """
 set_isolation!(r::BatchRunner, iters_per_sample::Real) =
     (check(ccall((:acme_batch_set_isolation, lib), Cint, (Ptr{Cvoid}, Cdouble), r.h, iters_per_sample)); r)
+
+"""
+    set_balance!(runner, mode)
+
+Placement of a launch's waves by their measured cost (`acme_batch_set_balance`): `-1` lets the library decide (the
+default: on when the launch has more blocks than the device has compute units), `0` switches it off, `1` on.
+What an instance computes does not depend on it.
+"""
+set_balance!(r::BatchRunner, mode::Integer) =
+    (check(ccall((:acme_batch_set_balance, lib), Cint, (Ptr{Cvoid}, Cint), r.h, mode)); r)
 
 """
     set_models!(runner, first, models)

@@ -731,6 +731,47 @@ def test_emulated_isolation_of_slow_instances(emu_lib):
     assert np.array_equal(r.run(u), ref.run(u))
 
 
+def test_emulated_balance_is_invisible(emu_lib, monkeypatch):
+    """acme_batch_set_balance: the waves (groups of 4 consecutive instances) are dealt to the launch's slots by the
+    Newton iterations they needed since the last placement -- heaviest first, the lightest on top of the heaviest when
+    the launch has two rounds of blocks -- and nothing anybody computes changes, bit for bit; the instances of an
+    incomplete last wave keep their slots.  (A "chip" of one compute unit, so that 26 instances are two rounds.)"""
+    from helpers import HS
+    monkeypatch.setenv("ACME_EMU_CUS", "1")
+    monkeypatch.setenv("ACME_BALANCE_MIN_SAMPLES", "20")
+    m = load("superover_var", HS)
+    N, T = 26, 30
+    u = sweep_inputs("superover_var", N, T, seed=5)
+    ref = emu_runner(emu_lib, m, N).set_balance(0)
+    r = emu_runner(emu_lib, m, N).set_balance(1)
+    assert np.array_equal(r.placement(), np.arange(N))
+    places = []
+    for k in range(3):
+        assert np.array_equal(r.run(u), ref.run(u)), k
+        places.append(r.placement())
+    assert np.array_equal(places[0], np.arange(N))             # the first launch had nothing to go by
+    assert not np.array_equal(places[1], np.arange(N))
+    # what the placement is: waves intact, ranked by the iterations of the launch before
+    per = ref.report_arrays()["iters_total"]
+    p = places[1]
+    assert sorted(p.tolist()) == list(range(N)) and p[24:].tolist() == [24, 25]
+    assert all(p[4 * q + j] == p[4 * q] + j and p[4 * q] % 4 == 0 for q in range(6) for j in range(4))
+    ra, rb = r.report_arrays(), ref.report_arrays()
+    for key in ("iters_total", "n_warn", "iters_max", "first_nonconverged"):
+        assert np.array_equal(ra[key], rb[key]), key
+    for a, b in zip(r.get_state(), ref.get_state()):
+        assert np.array_equal(a, b)
+    # first launch's weights -> second launch's slots: 4 heaviest in rank order, then the two lightest, lightest first
+    r2 = emu_runner(emu_lib, m, N).set_balance(1)
+    r2.run(u)
+    w = r2.report_arrays()["iters_total"][:24].reshape(6, 4).max(axis=1)
+    r2.run(u)
+    order = sorted(range(6), key=lambda k: (-w[k], k))
+    want = order[:4] + order[4:][::-1]
+    assert (r2.placement()[:24:4] // 4).tolist() == want
+    del per
+
+
 def test_emulated_mosfet_polynomial_cap_is_reported_by_the_abi(emu_lib):
     """The reference's MOSFET takes threshold / gain polynomials of any length (src/elements.jl:436-450); the element
     table holds 4 coefficients each -- more is refused by acme_model_add_subproblem itself, with a message."""

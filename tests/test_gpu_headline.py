@@ -327,3 +327,41 @@ def test_pathological_tail_literal_grid(hip_lib):
     first = ModelRunner(m, len(spot), lib=hip_lib)
     first.run(np.transpose(un[spot], (0, 2, 1)), check=False)
     assert first.report_arrays()["n_warn"].tolist() == warn.tolist()
+
+
+def test_balance_is_invisible_and_on_by_default(hip_lib):
+    """acme_batch_set_balance on the chip: a batch with more blocks than the device has compute units places its waves
+    by their measured cost from the second launch on (default), asynchronously on the launch's stream -- and every
+    output, counter and state is bit-identical to the same batch with the placement switched off; a batch of one round
+    of blocks is left alone."""
+    import torch
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    dev = torch.device("cuda", 0)
+    m = load("superover_var", CachingHomotopySolver)
+    N, T = 4608, 4200          # 288 blocks on 256 compute units; more than 4 096 samples per launch
+    idx = np.arange(N)
+    pots = np.stack([(idx // 256) / 19.0 * 0.97, ((idx // 16) % 16) / 15.0, (idx % 16) / 15.0], axis=1)
+    un = np.zeros((N, T, 4))
+    un[:, :, 0] = sine(T)[None, :]
+    un[:, :, 1:] = pots[:, None, :]
+    u = torch.from_numpy(un).to(dev)
+    ref = ModelRunner(m, N).set_balance(0)
+    r = ModelRunner(m, N)
+    for k in range(3):          # (back to back, no synchronisation in between: the placement kernels are stream-ordered)
+        y = r.run_torch(u)
+        yr = ref.run_torch(u)
+        assert torch.equal(y, yr), k
+    p = r.placement()
+    assert sorted(p.tolist()) == list(range(N)) and not np.array_equal(p, np.arange(N))
+    assert np.array_equal(p.reshape(-1, 4), p[::4, None] + np.arange(4)[None, :])      # waves intact
+    assert np.array_equal(ref.placement(), np.arange(N))
+    ra, rb = r.report_arrays(), ref.report_arrays()
+    for key in ("iters_total", "n_warn", "iters_max", "first_nonconverged", "first_nonfinite"):
+        assert np.array_equal(ra[key], rb[key]), key
+    for a, b in zip(r.get_state(), ref.get_state()):
+        assert np.array_equal(a, b)
+    small = ModelRunner(m, 1024)
+    for _ in range(2):
+        small.run_torch(u[:1024].contiguous())
+    assert np.array_equal(small.placement(), np.arange(1024))

@@ -13,7 +13,7 @@ from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel  # noqa: E402
 from acme_jl_amd.runner import ModelRunner  # noqa: E402
 
 dev = torch.device("cuda:0")
-N, T, STEPS = 8192, 4410, 40
+N, T, STEPS = 8192, 4410, int(os.environ.get("PROBE_STEPS", "40"))
 fixture, pots, amp = bench.grid_inputs("superover_grid", 0, 1, N, T * STEPS)
 m = DiscreteModel.load(os.path.join(bench.ROOT, "tests", "golden", fixture + ".json"), solver=CachingHomotopySolver)
 u = bench.make_u(torch, dev, m, pots, amp, N, T * STEPS)
