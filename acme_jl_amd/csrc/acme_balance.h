@@ -20,6 +20,10 @@
 // block b + CUs share a unit (of the pairings probed, this one gave the most).  With no more than two rounds the
 // heaviest waves fill the first round in order and the lightest wave goes on top of the heaviest; with more rounds the
 // order is plain heaviest-first (the dispatcher then places each block where a unit has become free).
+//
+// Slots can be empty (inst_map = -1): those an incomplete last wave leaves, and -- a developer's knob, ACME_WAVE_DENSITY --
+// those of waves deliberately filled with two or one instance (`per`); see wave_density in acme_api.inc for why the
+// library never does that by itself.
 #pragma once
 #include "acme_common.h"
 
@@ -27,21 +31,23 @@ namespace acme {
 
 struct BalArgs {
     const long long *report;    // [n][RW_WORDS]
-    long long *prev;            // [n]: RW_ITERS_TOTAL at the last balancing
-    unsigned *weight;           // [nw]
-    int *map;                   // [n]: slot -> instance
+    long long *prev;            // [n]: RW_ITERS_TOTAL at the last placement
+    unsigned *weight;           // [nu]
+    int *map;                   // [nu * BAL_SLOTS]: slot -> instance, -1: empty
     long long n;                // instances of the batch
-    int nw;                     // full waves (n / BAL_WAVE)
+    int per;                    // instances per wave: 1, 2 or 4
+    int nu;                     // waves = ceil(n / per)
     int first_round;            // wave slots of one round of blocks (waves per block x compute units)
 };
 
-constexpr int BAL_WAVE = 4;     // instances of a wave of the 16-lane kernel (64 lanes / GROUP)
+constexpr int BAL_SLOTS = 4;    // instance slots of a wave of the 16-lane kernel (64 lanes / GROUP)
 
-// thread k < nw (k == 0 also looks after the instances of an incomplete last wave: they keep their slots)
+// thread k < nu
 ACME_HD inline void bal_weight(const BalArgs &A, int k) {
     long long w = 0;
-    for (int j = 0; j < BAL_WAVE; ++j) {
-        const long long i = (long long)k * BAL_WAVE + j;
+    for (int j = 0; j < A.per; ++j) {
+        const long long i = (long long)k * A.per + j;
+        if (i >= A.n) break;
         const long long it = A.report[i * RW_WORDS + RW_ITERS_TOTAL];
         long long d = it - A.prev[i];
         if (d < 0) d = it;                    // (the report was reset in between)
@@ -49,28 +55,26 @@ ACME_HD inline void bal_weight(const BalArgs &A, int k) {
         w = d > w ? d : w;
     }
     A.weight[k] = w > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)w;
-    if (k == 0)
-        for (long long i = (long long)A.nw * BAL_WAVE; i < A.n; ++i) {
-            A.prev[i] = A.report[i * RW_WORDS + RW_ITERS_TOTAL];
-            A.map[i] = (int)i;
-        }
 }
 
-ACME_HD inline int bal_slot(int rank, int nw, int first_round) {
-    if (first_round > 0 && nw > first_round && nw <= 2 * first_round)
-        return rank < first_round ? rank : first_round + (nw - 1 - rank);
+ACME_HD inline int bal_slot(int rank, int nu, int first_round) {
+    if (first_round > 0 && nu > first_round && nu <= 2 * first_round)
+        return rank < first_round ? rank : first_round + (nu - 1 - rank);
     return rank;
 }
 
 ACME_HD inline void bal_place(const BalArgs &A, int k) {
     const unsigned wk = A.weight[k];
     int rank = 0;
-    for (int j = 0; j < A.nw; ++j) {
+    for (int j = 0; j < A.nu; ++j) {
         const unsigned wj = A.weight[j];
         rank += (wj > wk || (wj == wk && j < k)) ? 1 : 0;
     }
-    const int q = bal_slot(rank, A.nw, A.first_round);
-    for (int j = 0; j < BAL_WAVE; ++j) A.map[(long long)q * BAL_WAVE + j] = k * BAL_WAVE + j;
+    const int q = bal_slot(rank, A.nu, A.first_round);
+    for (int j = 0; j < BAL_SLOTS; ++j) {
+        const long long i = (long long)k * A.per + j;
+        A.map[(long long)q * BAL_SLOTS + j] = (j < A.per && i < A.n) ? (int)i : -1;
+    }
 }
 
 }  // namespace acme

@@ -78,11 +78,11 @@ __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
 // placement of the waves by their measured cost (acme_balance.h): one thread per wave
 __global__ __launch_bounds__(256) void acme_balance_weight_kernel(BalArgs A) {
     const int k = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (k < A.nw) bal_weight(A, k);
+    if (k < A.nu) bal_weight(A, k);
 }
 __global__ __launch_bounds__(256) void acme_balance_place_kernel(BalArgs A) {
     const int k = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (k < A.nw) bal_place(A, k);
+    if (k < A.nu) bal_place(A, k);
 }
 
 static const KernelEntry *find_kernel(const Dims &d) {
@@ -141,7 +141,7 @@ static inline int launch_generic(const GArgs &A, stream_t st) {
     return (int)hipGetLastError();
 }
 static inline int launch_balance(const BalArgs &A, stream_t st) {
-    const unsigned g = (unsigned)((A.nw + 255) / 256);
+    const unsigned g = (unsigned)((A.nu + 255) / 256);
     hipLaunchKernelGGL(acme_balance_weight_kernel, dim3(g), dim3(256), 0, st, A);
     hipLaunchKernelGGL(acme_balance_place_kernel, dim3(g), dim3(256), 0, st, A);
     return (int)hipGetLastError();

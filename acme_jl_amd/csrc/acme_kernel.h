@@ -788,9 +788,11 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     const int gib = wave * GROUPS_PER_WAVE + grp;  // group in block
     const long long slot = (long long)wv::bid() * INST_PER_BLOCK + gib;
     const bool per_inst = A.image_stride != 0;
-    const bool valid = slot < A.n_inst;
-    // (a launch over a subset of the batch: KArgs::inst_map)
-    const long long inst = (A.inst_map && valid) ? (long long)A.inst_map[slot] : slot;
+    // (a launch over a subset of the batch, or with the instances placed by the launcher: KArgs::inst_map -- slot ->
+    // instance, -1 for a slot left empty: a batch too small to give every SIMD its waves is spread thin)
+    const long long mapped = (A.inst_map && slot < A.n_inst) ? (long long)A.inst_map[slot] : slot;
+    const bool valid = slot < A.n_inst && mapped >= 0;
+    const long long inst = valid ? mapped : slot;
 
     // ---- LDS carve-up -------------------------------------------------------------------
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));   // the block's dynamic LDS starts at 0
@@ -822,6 +824,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 long long ii = (long long)wv::bid() * INST_PER_BLOCK + g;
                 if (ii >= A.n_inst) ii = A.n_inst - 1;
                 if (A.inst_map) ii = A.inst_map[ii];
+                if (ii < 0) ii = 0;              // (an empty slot: any image will do)
                 const double *src = A.image + ii * A.image_stride;
                 for (int i = tid; i < S::IMGN; i += nthreads) lds_img[g * S::IMGN + i] = src[S::IMG0 + i];
             }

@@ -121,7 +121,7 @@ class Library:
         L.acme_batch_release_host_buffers.argtypes = [vp]
         L.acme_batch_set_isolation.argtypes = [vp, C.c_double]
         L.acme_batch_set_balance.argtypes = [vp, C.c_int]
-        L.acme_batch_get_placement.argtypes = [vp, ip]
+        L.acme_batch_get_placement.argtypes = [vp, ip, C.POINTER(C.c_longlong)]
         L.acme_batch_set_progress_callback.argtypes = [vp, PROGRESS_FN, vp]
         L.acme_batch_solve.argtypes = [vp, C.c_int, dp, dp, ip, ip, C.c_int, vp]
         L.acme_batch_get_extrapolation_jacobian.argtypes = [vp, C.c_int, dp, C.c_int, vp]
@@ -261,9 +261,12 @@ class ModelRunner:
         return self
 
     def placement(self):
-        """slot -> instance of the next launch (``acme_batch_get_placement``; the identity while nothing is placed)"""
-        out = np.empty(self.n, dtype=np.int32)
-        self.lib.check(self.lib.L.acme_batch_get_placement(self.h, _ip(out)))
+        """slot -> instance of the last launch (``acme_batch_get_placement``): -1 = empty slot; the identity while
+        nothing is placed"""
+        n = C.c_longlong(0)
+        self.lib.check(self.lib.L.acme_batch_get_placement(self.h, None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.int32)
+        self.lib.check(self.lib.L.acme_batch_get_placement(self.h, _ip(out), None))
         return out
 
     def release_host_buffers(self):

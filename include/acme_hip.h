@@ -193,13 +193,15 @@ int acme_batch_set_isolation(acme_batch *b, double iters_per_sample);
  * the waves -- groups of 4 consecutive instances -- by the Newton iterations they needed since the last placement and
  * deal them to the launch's slots so that heavy and light waves share a SIMD (headline grid: 1.6 % over seconds 1-4 of a
  * signal, when the cells' costs differ most; nothing in the long steady state; tools/balance_probe.py).  No host synchronisation; what an instance computes does not depend on where it runs
- * (bit-identical results).  mode: -1 = the library decides (default: on when the launch has more blocks than the
- * device has compute units), 0 = off, 1 = on.  Not for batches the lane-per-instance or generic kernels run, nor
+ * (bit-identical results).  mode: -1 = the library decides (default: on when the launch has more waves than one round
+ * of blocks holds), 0 = off, 1 = on.  Not for batches the lane-per-instance or generic kernels run, nor
  * while acme_batch_set_isolation is in force. */
 int acme_batch_set_balance(acme_batch *b, int mode);
-/* diagnostics: slot_to_instance[N] of the placement the next launch would use (the identity while there is none);
- * completes the batch's outstanding work first */
-int acme_batch_get_placement(acme_batch *b, int *slot_to_instance);
+/* diagnostics: the placement the last launch used -- *n_slots instance slots (a multiple of 4: a wave has four), slot ->
+ * instance in slot_to_instance[*n_slots], -1 for a slot left empty (an incomplete last wave's); at most 4 N slots; the
+ * identity over N slots while nothing has been placed.
+ * Either pointer may be null.  Completes the batch's outstanding work first. */
+int acme_batch_get_placement(acme_batch *b, int *slot_to_instance, long long *n_slots);
 
 /* The solver plugin contract, batched (src/solvers.jl:207-236, 268-302): for every instance
  *   z = solve(solver, p); converged = hasconverged(solver); iters = needediterations(solver)

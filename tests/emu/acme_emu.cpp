@@ -244,14 +244,15 @@ static inline int launch_generic(const GArgs &A, stream_t) {
 }
 // placement of the waves by their measured cost (acme_balance.h): the two passes, one "thread" after the other
 static inline int launch_balance(const BalArgs &A, stream_t) {
-    for (int k = 0; k < A.nw; ++k) bal_weight(A, k);
-    for (int k = 0; k < A.nw; ++k) bal_place(A, k);
+    for (int k = 0; k < A.nu; ++k) bal_weight(A, k);
+    for (int k = 0; k < A.nu; ++k) bal_place(A, k);
     return 0;
 }
-// (ACME_EMU_CUS: a small "chip", so that batches of a few dozen instances have two rounds of blocks)
+// (ACME_EMU_CUS: a small "chip", so that batches of a few dozen instances have two rounds of blocks; without it the
+// number of compute units is unknown and the launcher places nothing -- full waves cost the emulator least)
 static inline int cu_count(int *n) {
     const char *e = getenv("ACME_EMU_CUS");
-    *n = e ? atoi(e) : 256;
+    *n = e ? atoi(e) : 0;
     return 0;
 }
 // the fiber scheduler below is not re-entrant: asynchronous runs (acme_batch_run_async) take turns

@@ -734,8 +734,8 @@ def test_emulated_isolation_of_slow_instances(emu_lib):
 def test_emulated_balance_is_invisible(emu_lib, monkeypatch):
     """acme_batch_set_balance: the waves (groups of 4 consecutive instances) are dealt to the launch's slots by the
     Newton iterations they needed since the last placement -- heaviest first, the lightest on top of the heaviest when
-    the launch has two rounds of blocks -- and nothing anybody computes changes, bit for bit; the instances of an
-    incomplete last wave keep their slots.  (A "chip" of one compute unit, so that 26 instances are two rounds.)"""
+    the launch has two rounds of blocks -- and nothing anybody computes changes, bit for bit; the slots an incomplete
+    last wave leaves are empty.  (A "chip" of one compute unit, so that 26 instances are two rounds.)"""
     from helpers import HS
     monkeypatch.setenv("ACME_EMU_CUS", "1")
     monkeypatch.setenv("ACME_BALANCE_MIN_SAMPLES", "20")
@@ -750,26 +750,56 @@ def test_emulated_balance_is_invisible(emu_lib, monkeypatch):
         assert np.array_equal(r.run(u), ref.run(u)), k
         places.append(r.placement())
     assert np.array_equal(places[0], np.arange(N))             # the first launch had nothing to go by
-    assert not np.array_equal(places[1], np.arange(N))
-    # what the placement is: waves intact, ranked by the iterations of the launch before
-    per = ref.report_arrays()["iters_total"]
-    p = places[1]
-    assert sorted(p.tolist()) == list(range(N)) and p[24:].tolist() == [24, 25]
-    assert all(p[4 * q + j] == p[4 * q] + j and p[4 * q] % 4 == 0 for q in range(6) for j in range(4))
+    assert np.array_equal(ref.placement(), np.arange(N))
+    p = places[1]                                              # 7 waves, 28 slots
+    assert len(p) == 28 and sorted(p[p >= 0].tolist()) == list(range(N)) and (p < 0).sum() == 2
+    for q in range(7):
+        w = p[4 * q:4 * q + 4]
+        assert w[0] % 4 == 0 and all(w[j] == (w[0] + j if w[0] + j < N else -1) for j in range(4))
     ra, rb = r.report_arrays(), ref.report_arrays()
     for key in ("iters_total", "n_warn", "iters_max", "first_nonconverged"):
         assert np.array_equal(ra[key], rb[key]), key
     for a, b in zip(r.get_state(), ref.get_state()):
         assert np.array_equal(a, b)
-    # first launch's weights -> second launch's slots: 4 heaviest in rank order, then the two lightest, lightest first
+    # first launch's weights -> second launch's slots: 4 heaviest in rank order, then the three lightest, lightest first
     r2 = emu_runner(emu_lib, m, N).set_balance(1)
     r2.run(u)
-    w = r2.report_arrays()["iters_total"][:24].reshape(6, 4).max(axis=1)
+    it = np.concatenate([r2.report_arrays()["iters_total"], [0, 0]])
+    w = it.reshape(7, 4).max(axis=1)
     r2.run(u)
-    order = sorted(range(6), key=lambda k: (-w[k], k))
+    order = sorted(range(7), key=lambda k: (-w[k], k))
     want = order[:4] + order[4:][::-1]
-    assert (r2.placement()[:24:4] // 4).tolist() == want
-    del per
+    assert (r2.placement()[::4] // 4).tolist() == want
+
+
+def test_emulated_empty_slots_in_the_placement(emu_lib, monkeypatch):
+    """Slots of a launch may be empty (inst_map = -1).  The library leaves only those of an incomplete last wave empty;
+    the developer's knob ACME_WAVE_DENSITY fills waves with two or one instance instead of four, which exercises them
+    everywhere: across launches, sub-problems and the state entry points, bit-identical to full waves."""
+    from helpers import HS
+    from acme_jl_amd.model import CachingHomotopySolver
+    for name, solver, N, per in (("superover_var", CachingHomotopySolver, 5, 1), ("birdie_var", HS, 11, 2)):
+        m = load(name, solver)
+        T = 50
+        u = sweep_inputs(name, N, T, seed=3)
+        monkeypatch.delenv("ACME_WAVE_DENSITY", raising=False)
+        ref = emu_runner(emu_lib, m, N)
+        y_ref = [ref.run(u), ref.run(u)]
+        assert np.array_equal(ref.placement(), np.arange(N))
+        monkeypatch.setenv("ACME_WAVE_DENSITY", str(per))
+        r = emu_runner(emu_lib, m, N)
+        y = [r.run(u), r.run(u)]
+        p = r.placement()
+        nu = -(-N // per)
+        assert len(p) == 4 * nu and sorted(p[p >= 0].tolist()) == list(range(N)), (name, p)
+        assert all((p[4 * q:4 * q + 4] >= 0).sum() == min(per, N - per * (p[4 * q] // per)) for q in range(nu)), (name, p)
+        for a, b in zip(y, y_ref):
+            assert np.array_equal(a, b), name
+        ra, rb = r.report_arrays(), ref.report_arrays()
+        for key in ("iters_total", "n_warn", "iters_max"):
+            assert np.array_equal(ra[key], rb[key]), (name, key)
+        for a, b in zip(r.get_state(), ref.get_state()):
+            assert np.array_equal(a, b), name
 
 
 def test_emulated_mosfet_polynomial_cap_is_reported_by_the_abi(emu_lib):

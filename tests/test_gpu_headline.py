@@ -333,7 +333,7 @@ def test_balance_is_invisible_and_on_by_default(hip_lib):
     """acme_batch_set_balance on the chip: a batch with more blocks than the device has compute units places its waves
     by their measured cost from the second launch on (default), asynchronously on the launch's stream -- and every
     output, counter and state is bit-identical to the same batch with the placement switched off; a batch of one round
-    of blocks is left alone."""
+    of blocks is left as it comes; slots may be empty."""
     import torch
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
@@ -361,7 +361,18 @@ def test_balance_is_invisible_and_on_by_default(hip_lib):
         assert np.array_equal(ra[key], rb[key]), key
     for a, b in zip(r.get_state(), ref.get_state()):
         assert np.array_equal(a, b)
-    small = ModelRunner(m, 1024)
-    for _ in range(2):
-        small.run_torch(u[:1024].contiguous())
+    # a batch of one round of blocks is left as it comes; empty slots (the developer's knob: one instance per wave)
+    small, sthin = ModelRunner(m, 1024), ModelRunner(m, 1024)
+    us = u[:1024].contiguous()
+    import os
+    for k in range(2):
+        ys = small.run_torch(us)
+        os.environ["ACME_WAVE_DENSITY"] = "1"
+        try:
+            yt = sthin.run_torch(us)
+        finally:
+            del os.environ["ACME_WAVE_DENSITY"]
+        assert torch.equal(ys, yt), k
     assert np.array_equal(small.placement(), np.arange(1024))
+    ps = sthin.placement()
+    assert len(ps) == 4096 and sorted(ps[ps >= 0].tolist()) == list(range(1024)) and (ps.reshape(-1, 4)[:, 1:] < 0).all()
