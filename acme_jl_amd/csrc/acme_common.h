@@ -229,6 +229,13 @@ struct KArgs {
     int lane_density;
     int *cflags;             // [n_inst]: bit 0 = the extrapolation origin may lie OFF the linear rows' subspace
                              // (initial solution, acme_batch_set_state, an iterate accepted without a Newton step)
+    // samples between the rows of consecutive instances in u / y (0: T -- the launch covers whole rows).  A host-buffer
+    // run reads or writes a time slice of the caller's arrays in place: rows T_total apart, T of them per launch
+    long long u_stride, y_stride;
+    // streamed host run: u is being copied into HBM while the kernel runs; *u_ready (host memory, written by the host
+    // after each chunk of the copy has landed) = number of samples of every row that are there.  A wave that gets ahead
+    // of the copy waits.  nullptr: all of u is there.
+    const long long *u_ready;
 };
 
 }  // namespace acme

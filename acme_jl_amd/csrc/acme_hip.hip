@@ -3,6 +3,7 @@
 // Host side is deliberately thin: pack the model once, keep per-instance state resident in
 // HBM, launch one kernel per run! call on the caller's stream.  No CPU fallback exists:
 // without a usable HIP device every compute entry point fails with ACME_ERR_NO_DEVICE.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -146,6 +147,14 @@ static inline int launch_balance(const BalArgs &A, stream_t st) {
     hipLaunchKernelGGL(acme_balance_place_kernel, dim3(g), dim3(256), 0, st, A);
     return (int)hipGetLastError();
 }
+// a word of host memory the device can read while a kernel runs (streamed host runs: KArgs::u_ready)
+static inline int flag_alloc(long long **h, const long long **d) {
+    hipError_t e = hipHostMalloc((void **)h, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipHostGetDevicePointer((void **)d, *h, 0);
+}
+static inline int flag_free(long long *h) { return h ? (int)hipHostFree(h) : 0; }
+static inline bool kernels_run_async() { return true; }
 static inline int cu_count(int *n) {
     int d = 0;
     hipError_t e = hipGetDevice(&d);

@@ -1957,10 +1957,28 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     // small shapes, which have the registers, requesting the tile a whole chunk ahead gained nothing).
     // (Global pointers are recomputed here, once per 16 samples, for the same reason.)
     double upre[S::NUR];
+    long long u_seen = 0;         // (streamed host run: the last value of *A.u_ready this wave has read)
     auto fetch_u = [&](long long n0) ACME_LAMBDA {
-        const double *ug = A.u + ((valid ? inst : 0) * T + n0) * nu_io;
+        const double *ug = A.u + ((valid ? inst : 0) * (A.u_stride ? A.u_stride : T) + n0) * nu_io;
         long long cnt = T - n0;
         if (cnt > S::CH) cnt = S::CH;
+        if (ACME_RARE(A.u_ready != nullptr)) {
+            // streamed host run: the tile may still be on its way into HBM -- wait for the host's word that it has
+            // landed (a wave gets ahead of the copy engine only at the very start of a run), then read it past the
+            // caches (the copy engine wrote it after this kernel's launch)
+            if (u_seen < n0 + cnt) {
+                while ((u_seen = wv::load_system(A.u_ready)) < n0 + cnt) wv::nap();
+                wv::acquire_system();      // (drops what the caches hold: a line may straddle the end of what had landed before)
+            }
+#ifdef ACME_STREAM_UNCACHED
+            sfor<0, NU>([&](auto ic) ACME_LAMBDA {
+                constexpr int i = decltype(ic)::value;
+                int e = lig + GROUP * i;
+                upre[i] = (valid && e < (int)cnt * nu_io) ? wv::load_system(&ug[e]) : 0.0;
+            });
+            return;
+#endif
+        }
         sfor<0, NU>([&](auto ic) ACME_LAMBDA {
             constexpr int i = decltype(ic)::value;
             int e = lig + GROUP * i;
@@ -2273,7 +2291,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         }
         // flush the y tile, coalesced
         if (NY > 0 && !solve_mode) {
-            double *yg = A.y + ((valid ? inst : 0) * T + n0) * ny_io;
+            double *yg = A.y + ((valid ? inst : 0) * (A.y_stride ? A.y_stride : T) + n0) * ny_io;
             wv::wave_fence();
             for (int e = lig; e < cnt * ny_io; e += GROUP)
                 if (valid) yg[e] = ybuf[(e / ny_io) * NY + (e % ny_io)];

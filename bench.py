@@ -332,24 +332,38 @@ def host_buffer_leg(runner, u, N, T, model):
     ts = [call(uh, yh) for _ in range(2)]
     out.update(first_call_ms=1e3 * t_first, steady_ms=1e3 * min(ts), steady_value=N * T / min(ts),
                first_call_value=N * T / t_first, y_abs_sum=float(np.abs(np.nan_to_num(yh)).sum()))
-    os.environ["ACME_HOST_ZEROCOPY"] = "0"
-    try:
-        t_staged = min(call(uh, yh) for _ in range(2))
-    finally:
-        os.environ.pop("ACME_HOST_ZEROCOPY", None)
+    extra = {}
+    for key, env in (("inplace", {"ACME_HOST_SLICES": "1"}), ("staged", {"ACME_HOST_ZEROCOPY": "0"})):
+        os.environ.update(env)
+        try:
+            extra[key] = min(call(uh, yh) for _ in range(2))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    if os.environ.get("ACME_BENCH_HOST_SLICES"):        # (developer: sweep of the default pipeline's slice count)
+        for ns in os.environ["ACME_BENCH_HOST_SLICES"].split(","):
+            os.environ["ACME_HOST_SLICES"] = ns
+            try:
+                out["slices_%s_ms" % ns] = 1e3 * min(call(uh, yh) for _ in range(2))
+            finally:
+                os.environ.pop("ACME_HOST_SLICES", None)
     runner.release_host_buffers()
     os.environ["ACME_HOST_REGISTER"] = "0"
     try:
         t_page = min(call(uh, yh) for _ in range(2))
     finally:
         os.environ.pop("ACME_HOST_REGISTER", None)
-    out.update(staged_ms=1e3 * t_staged, staged_value=N * T / t_staged,
+    out.update(inplace_ms=1e3 * extra["inplace"], inplace_value=N * T / extra["inplace"],
+               staged_ms=1e3 * extra["staged"], staged_value=N * T / extra["staged"],
                pageable_ms=1e3 * t_page, pageable_value=N * T / t_page,
                note="acme_batch_run(ACME_MEM_HOST) on the timed batch, continuing the signal.  first call: page-locks the "
-                    "caller's arrays; steady: the same arrays again -- ZERO COPY, the kernel reads u from and writes y to "
-                    "the locked host arrays over the bus, one launch; staged (ACME_HOST_ZEROCOPY=0): 24 time slices "
-                    "through HBM, copies overlapped with the kernel on two streams; pageable (ACME_HOST_REGISTER=0): "
-                    "the staged pipeline from unlocked memory")
+                    "caller's arrays; steady: the same arrays again -- the default, STREAMED pipeline: one launch over the whole "
+                    "run, y written to the locked host array by the kernel itself, u copied into an HBM staging buffer by "
+                    "the copy engine 128 samples of every row at a time while the kernel runs (a wave that gets ahead of "
+                    "the copy waits: KArgs::u_ready); inplace (ACME_HOST_SLICES=1): one launch, u and y both in place over "
+                    "the bus; staged (ACME_HOST_ZEROCOPY=0): "
+                    "24 time slices, u and y both through HBM, copies overlapped with the kernel on two streams; pageable "
+                    "(ACME_HOST_REGISTER=0): the staged pipeline from unlocked memory")
     return out
 
 

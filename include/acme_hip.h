@@ -141,9 +141,11 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
                             const acme_model *const *models);
 
 /* run!(runner, y, u): advance every instance by T samples (src/ACME.jl:650-664).
- * mem = ACME_MEM_HOST: u/y are host buffers, staged through HBM by the library (runs of 4096+
- *   samples in time slices whose copies overlap the kernel on a second stream); the call returns
- *   when y is complete;
+ * mem = ACME_MEM_HOST: u/y are host buffers.  Runs of 4096+ samples are STREAMED: one launch; the kernel writes
+ *   y to the (page-locked, mapped) array itself and reads u from an HBM staging buffer the copy engine fills
+ *   while the kernel runs (waves that get ahead of the copy wait) -- the device-resident rate.  With a progress
+ *   callback installed, for memory that cannot be page-locked, and for the lane-per-instance and generic
+ *   kernels: time slices whose copies overlap the kernel.  The call returns when y is complete;
  * mem = ACME_MEM_DEVICE: u/y are device pointers on the batch's device and `stream` is the
  * hipStream_t to launch on (NULL = default stream); the call is then asynchronous. */
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
@@ -158,8 +160,9 @@ int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int m
 int acme_batch_release_host_buffers(acme_batch *b);
 /* @showprogress of run!(runner, y, u) (src/ACME.jl:587-604,653): `fn(user, samples_done, samples_total)`
  * is called on the calling thread (the worker thread of an asynchronous run) after every time slice of a
- * host-buffer run -- up to 24 per run of 4096+ samples -- and once at the end of any other run.  fn = NULL
- * removes it.  The callback must not call into the batch. */
+ * host-buffer run -- 8 to 24 per run of 4096+ samples; a callback makes such a run sliced rather than streamed,
+ * at ~0.91 of the speed -- and once at the end of any other run.  fn = NULL removes it.  The callback must not
+ * call into the batch. */
 typedef void (*acme_progress_fn)(void *user, long long samples_done, long long samples_total);
 int acme_batch_set_progress_callback(acme_batch *b, acme_progress_fn fn, void *user);
 

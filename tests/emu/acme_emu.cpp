@@ -248,6 +248,10 @@ static inline int launch_balance(const BalArgs &A, stream_t) {
     for (int k = 0; k < A.nu; ++k) bal_place(A, k);
     return 0;
 }
+// streamed host runs: a launch here is synchronous -- the host copies everything first (acme_api.inc)
+static inline int flag_alloc(long long **h, const long long **d) { *h = (long long *)calloc(8, 8); *d = *h; return *h ? 0 : 1; }
+static inline int flag_free(long long *h) { free(h); return 0; }
+static inline bool kernels_run_async() { return false; }
 // (ACME_EMU_CUS: a small "chip", so that batches of a few dozen instances have two rounds of blocks; without it the
 // number of compute units is unknown and the launcher places nothing -- full waves cost the emulator least)
 static inline int cu_count(int *n) {

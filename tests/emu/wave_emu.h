@@ -252,6 +252,11 @@ ACME_DEV double settle(double v) { return v; }
 ACME_DEV int keepi(int v) { return v; }
 ACME_DEV void touch(double) {}
 ACME_DEV int opaque(int v) { return v; }
+// (streamed host runs: the emulator launches synchronously, the host has copied everything before)
+ACME_DEV long long load_system(const long long *p) { return *p; }
+ACME_DEV double load_system(const double *p) { return *p; }
+ACME_DEV void acquire_system() {}
+ACME_DEV void nap() {}
 ACME_DEV unsigned long long pin(unsigned long long m) { return m; }
 ACME_DEV double sconst(double v) { return v; }
 ACME_DEV double clamp_s(double k, double lo, double hi) { return fmin(fmax(k, lo), hi); }

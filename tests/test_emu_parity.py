@@ -657,6 +657,43 @@ def test_emulated_progress_callback_and_host_buffer_release(emu_lib):
     r.release_host_buffers()                   # idempotent
 
 
+def test_emulated_host_buffer_pipelines_agree(emu_lib, monkeypatch):
+    """run! through host buffers with the 16-lane kernel: the default, streamed pipeline (one launch, u copied into HBM
+    chunk by chunk -- KArgs::u_ready; the emulator launches synchronously, so here the copy comes first -- y written in
+    place), the sliced one (ACME_HOST_SLICES: y in place, the first time slice of u read in place, the following ones
+    staged under the kernel of the slice before; KArgs::u_stride / y_stride), the whole run in place
+    (ACME_HOST_SLICES=1) and the fully staged pipeline (ACME_HOST_ZEROCOPY=0) give the same bits, the sliced ones
+    report progress slice by slice, and the result is the oracle's."""
+    monkeypatch.setenv("ACME_LANE_KERNEL", "0")
+    monkeypatch.setenv("ACME_HOST_REGISTER_MIN", "1024")        # (the library page-locks arrays of 1 MB and more)
+    m = load("diodeclipper")
+    from acme_jl_amd.runner import ModelRunner
+    N, T = 3, 4500
+    u = sweep_inputs("diodeclipper", N, T)
+    out = {}
+    for name, env in (("default", {}), ("8 slices", {"ACME_HOST_SLICES": "8"}), ("in place", {"ACME_HOST_SLICES": "1"}),
+                      ("staged", {"ACME_HOST_ZEROCOPY": "0"}), ("3 slices", {"ACME_HOST_SLICES": "3"}),
+                      ("not streamed", {"ACME_HOST_STREAM": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        seen = []
+        # (a progress callback asks for time slices: the streamed pipeline is one launch)
+        r = ModelRunner(m, N, lib=emu_lib, showprogress=False if name == "default" else lambda done, total: seen.append((done, total)))
+        y1 = r.run(u)
+        y2 = r.run(u[:, :, :4200])                 # (a second call on a sub-range of the same arrays' shape)
+        out[name] = (y1, y2, [d for d, _ in seen])
+        for k in env:
+            monkeypatch.delenv(k)
+    for name in ("8 slices", "in place", "staged", "3 slices", "not streamed"):
+        assert np.array_equal(out[name][0], out["default"][0]) and np.array_equal(out[name][1], out["default"][1]), name
+    assert out["8 slices"][2][:5] == [1024, 2048, 3072, 4096, 4500]         # 8 wanted, 1 024 samples at least: 5 slices
+    assert out["not streamed"][2][:5] == [1024, 2048, 3072, 4096, 4500]
+    assert out["in place"][2][:1] == [4500]
+    assert out["3 slices"][2][:3] == [1504, 3008, 4500]
+    yref, _ = oracle_run(m, u)
+    assert_close(out["default"][0], yref, rtol=1e-12)
+
+
 def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):
     """Models beyond every tuned kernel shape (20 unknowns, 6 sub-problems, 40 states) run in the generic
     lane-per-instance kernel and walk the oracle's path (identical iteration totals, outputs to rounding), on both

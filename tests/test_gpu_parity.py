@@ -676,36 +676,44 @@ def test_lane_kernel_cache_layout(hip_lib, monkeypatch):
 
 @pytest.mark.gpu
 def test_host_buffer_paths_agree_bit_for_bit(hip_lib, monkeypatch):
-    """run! through host buffers (what the Julia binding calls): zero copy (the kernel reads u / writes y in the
-    caller's page-locked arrays, one launch), the staged pipeline (24 time slices through HBM), the pageable path
-    and the device-resident run are the same kernel on the same numbers -- bit-identical outputs, reports and state;
-    the page-locked arrays are released on demand and a progress callback sees the run."""
+    """run! through host buffers (what the Julia binding calls): the default, streamed pipeline (ONE launch; u copied
+    into HBM chunk by chunk while the kernel runs, waves that get ahead of the copy wait; y written in place), the sliced
+    one a progress callback gets (y in place, u read in place for the first time slice and staged for the others), the whole run in place (one launch: the
+    kernel reads u / writes y in the caller's page-locked arrays), the fully staged pipeline (24 time slices through
+    HBM), the pageable path and the device-resident run are the same kernel on the same numbers -- bit-identical
+    outputs, reports and state; the page-locked arrays are released on demand and a progress callback sees the run."""
     import ctypes as C
     import torch
     from acme_jl_amd.runner import ACME_MEM_HOST, ModelRunner
     m = load("superover_var")
-    N, T = 64, 4500
+    N, T = 64, 4501                # (rows of 144 032 bytes: not a multiple of a cache line)
     u = sweep_inputs("superover_var", N, T, seed=9)
     ub = np.ascontiguousarray(np.transpose(u, (0, 2, 1)))        # [N][T][nu]: the ABI's layout (> 1 MB: page-locked)
     dp = C.POINTER(C.c_double)
     outs = {}
-    for mode, env in (("zero copy", {}), ("staged", {"ACME_HOST_ZEROCOPY": "0"}), ("pageable", {"ACME_HOST_REGISTER": "0"})):
-        for k in ("ACME_HOST_ZEROCOPY", "ACME_HOST_REGISTER"):
+    for mode, env in (("default", {}), ("sliced", {}), ("in place", {"ACME_HOST_SLICES": "1"}), ("3 slices", {"ACME_HOST_SLICES": "3"}),
+                      ("streamed, 16-sample chunks", {"ACME_HOST_STREAM_CHUNK": "16"}),
+                      ("staged", {"ACME_HOST_ZEROCOPY": "0"}), ("pageable", {"ACME_HOST_REGISTER": "0"})):
+        for k in ("ACME_HOST_ZEROCOPY", "ACME_HOST_REGISTER", "ACME_HOST_SLICES", "ACME_HOST_STREAM_CHUNK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         seen = []
-        r = ModelRunner(m, N, lib=hip_lib, showprogress=lambda d, t: seen.append((d, t)))
+        # (the default is the streamed pipeline -- one launch, u copied in while the kernel runs -- unless a progress
+        # callback asks for time slices: "default" runs without one, "sliced" is what a callback gets)
+        streamed = mode == "default" or mode.startswith("streamed")
+        cb = False if streamed else (lambda d, t: seen.append((d, t)))
+        r = ModelRunner(m, N, lib=hip_lib, showprogress=cb)
         yb = np.full((N, T, m.ny), np.nan)
         for _ in range(2):       # (the second call finds the arrays page-locked)
-            r2 = ModelRunner(m, N, lib=hip_lib, showprogress=lambda d, t: seen.append((d, t)))
+            r2 = ModelRunner(m, N, lib=hip_lib, showprogress=cb)
             r2.lib.check(r2.lib.L.acme_batch_run(r2.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
             r2.release_host_buffers()
         r.lib.check(r.lib.L.acme_batch_run(r.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
-        assert seen and seen[-1] == (T, T)
+        assert streamed or (seen and seen[-1] == (T, T))
         outs[mode] = (yb.copy(), r.report_arrays()["iters_total"].copy(), [a.copy() for a in r.get_state()])
         r.release_host_buffers()
-    for k in ("ACME_HOST_ZEROCOPY", "ACME_HOST_REGISTER"):
+    for k in ("ACME_HOST_ZEROCOPY", "ACME_HOST_REGISTER", "ACME_HOST_SLICES", "ACME_HOST_STREAM_CHUNK"):
         monkeypatch.delenv(k, raising=False)
     r = ModelRunner(m, N, lib=hip_lib)
     yd = r.run_torch(torch.from_numpy(ub).cuda()).cpu().numpy()
