@@ -769,7 +769,9 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, dou
 // its own so that its pointers and branches stay out of the hot one.  MODE_JAC: one pass that exports every instance's
 // get_extrapolation_jacobian(solver) = -(J \ Jp) at its extrapolation origin (src/solvers.jl:198-201),
 // a separate, small kernel so that its extra registers and code stay out of the hot one.
-enum { MODE_RUN = 0, MODE_JAC = 1, MODE_SOLVE = 2 };
+// MODE_RUN_STREAM: run! whose u is still being copied into HBM while the kernel runs (KArgs::u_ready; streamed
+// host-buffer runs) -- a variant of its own: the check in the tile fetch cost the lone waves of BASELINE config 5 3.9 %.
+enum { MODE_RUN = 0, MODE_JAC = 1, MODE_SOLVE = 2, MODE_RUN_STREAM = 3 };
 template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
     constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT, NSUB = S::NSUBr;
@@ -1962,7 +1964,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         const double *ug = A.u + ((valid ? inst : 0) * (A.u_stride ? A.u_stride : T) + n0) * nu_io;
         long long cnt = T - n0;
         if (cnt > S::CH) cnt = S::CH;
-        if (ACME_RARE(A.u_ready != nullptr)) {
+        if constexpr (MODE == MODE_RUN_STREAM) {
             // streamed host run: the tile may still be on its way into HBM -- wait for the host's word that it has
             // landed (a wave gets ahead of the copy engine only at the very start of a run), then read it past the
             // caches (the copy engine wrote it after this kernel's launch)

@@ -18,6 +18,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, S::OCC) void acme_run_kernel(
     wave_main<S, MODE_RUN, LOW>(A, acme_lds);
 }
 
+// run! of a streamed host-buffer run (wave_main MODE_RUN_STREAM: u arrives in HBM while the kernel runs)
+template <class S, bool LOW>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, S::OCC) void acme_run_stream_kernel(KArgs A) {
+    extern __shared__ double acme_lds[];
+    wave_main<S, MODE_RUN_STREAM, LOW>(A, acme_lds);
+}
+
 // the small companion kernel: get_extrapolation_jacobian for every instance (wave_main MODE_JAC)
 template <class S, bool LOW>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, S::OCC) void acme_jac_kernel(KArgs A) {
@@ -43,14 +50,19 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
 // the three 16-lane kernels of one shape in one placement (LDS / LOW): entry points for
 // hipFuncSetAttribute and launchers
 struct KernelFns {
-    const void *fn = nullptr, *fn_jac = nullptr, *fn_solve = nullptr;
+    const void *fn = nullptr, *fn_jac = nullptr, *fn_solve = nullptr, *fn_stream = nullptr;
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
+    int (*launch_stream)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
     int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t) = nullptr;
 };
 
 template <class S, bool LOW> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
     hipLaunchKernelGGL((acme_run_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
+    return (int)hipGetLastError();
+}
+template <class S, bool LOW> static int launch_stream_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((acme_run_stream_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
     return (int)hipGetLastError();
 }
 template <class S, bool LOW> static int launch_jac_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
@@ -65,6 +77,10 @@ template <class S, bool LOW> static KernelFns make_fns() {
     KernelFns f;
     f.fn = (const void *)acme_run_kernel<S, LOW>;
     f.launch = &launch_shape<S, LOW>;
+    if constexpr (S::NU > 0) {       // (a model without inputs has nothing to stream)
+        f.fn_stream = (const void *)acme_run_stream_kernel<S, LOW>;
+        f.launch_stream = &launch_stream_shape<S, LOW>;
+    }
     if constexpr (S::NN > 0) {       // (linear models have no nonlinear solver)
         f.fn_jac = (const void *)acme_jac_kernel<S, LOW>;
         f.fn_solve = (const void *)acme_solve_kernel<S, LOW>;

@@ -116,8 +116,9 @@ void run_block(int bid, void (*entry)(void *), void *arg) {
 // kernel table
 // ------------------------------------------------------------------------------------------
 struct KernelFns {
-    const void *fn = nullptr, *fn_jac = nullptr, *fn_solve = nullptr;
+    const void *fn = nullptr, *fn_jac = nullptr, *fn_solve = nullptr, *fn_stream = nullptr;
     int (*launch)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
+    int (*launch_stream)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
     int (*launch_jac)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
     int (*launch_solve)(const KArgs &, unsigned grid, size_t lds_bytes, void *) = nullptr;
 };
@@ -135,12 +136,14 @@ struct LaunchCtx {
     double *lds;
 };
 
-// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel, 3: solve kernel; LOW: the LOW-LDS variant
+// KIND 0: run kernel, 1: Jacobian export, 2: lane-per-instance run kernel, 3: solve kernel, 4: run kernel of a streamed
+// host-buffer run; LOW: the LOW-LDS variant
 template <class S, int KIND, bool LOW> static void fiber_entry(void *p) {
     LaunchCtx *c = (LaunchCtx *)p;
     if constexpr (KIND == 0) wave_main<S, MODE_RUN, LOW>(*c->A, c->lds);
     else if constexpr (KIND == 1) { if constexpr (S::NN > 0) wave_main<S, MODE_JAC, LOW>(*c->A, c->lds); }
     else if constexpr (KIND == 3) { if constexpr (S::NN > 0) wave_main<S, MODE_SOLVE, LOW>(*c->A, c->lds); }
+    else if constexpr (KIND == 4) { if constexpr (S::NU > 0) wave_main<S, MODE_RUN_STREAM, LOW>(*c->A, c->lds); }
     else { if constexpr (LaneShape<S>::supported) lane_main<S>(*c->A, c->lds); }
 }
 
@@ -165,6 +168,10 @@ template <class S, bool LOW> static KernelFns make_fns() {
     if constexpr (LOW && !S::HAS_LOW) return f;
     f.fn = &emu_fn_tag;
     f.launch = &launch_any<S, 0, LOW>;
+    if constexpr (S::NU > 0) {
+        f.fn_stream = &emu_fn_tag;
+        f.launch_stream = &launch_any<S, 4, LOW>;
+    }
     if constexpr (S::NN > 0) {
         f.fn_jac = f.fn_solve = &emu_fn_tag;
         f.launch_jac = &launch_any<S, 1, LOW>;
