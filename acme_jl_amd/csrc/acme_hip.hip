@@ -51,7 +51,7 @@ template <class S> static int lane_lds(bool caching) {
 template <class S> static KernelEntry make_entry(int index) {
     ShapeFns f;
     if (!(acme_shape_fns_part0(index, &f) || acme_shape_fns_part1(index, &f) || acme_shape_fns_part2(index, &f) ||
-          acme_shape_fns_part3(index, &f)))
+          acme_shape_fns_part3(index, &f) || acme_shape_fns_part4(index, &f) || acme_shape_fns_part5(index, &f)))
         abort();
     return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB, S::NL}, f.lds, f.low, f.fn_lane,
                        S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,

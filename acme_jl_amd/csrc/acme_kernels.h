@@ -117,16 +117,17 @@ template <class S> static ShapeFns make_shape_fns() {
 // The kernels are instantiated in ACME_NPARTS translation units (acme_hip_part<k>.hip: the shapes with
 // shape_part(number in ACME_SHAPES) == k), compiled in parallel: the run kernel of one shape alone is
 // 10 ... 30 thousand instructions.  Each part answers for its own shapes.
-constexpr int ACME_NPARTS = 4;
+constexpr int ACME_NPARTS = 6;
 // Which part a shape lives in.  Not only for build time: the parts are compiled with different instruction
 // schedulers (__graft_entry__.py: HIP_UNIT_FLAGS).  Part 0 -- the smallest models, whose lane-per-instance kernels
 // prefer the compiler's default scheduler (the diode clipper sweep loses 1.2 % with max-ilp) -- and the condensed
-// headline kernel (short of registers: longer live ranges cost it 0.7 %); parts 1-3 with -amdgpu-sched-strategy=max-ilp (birdie +3.9 %, config 4 +1.4 %,
-// headline +0.2 %; max-memory-clause: -0.6 ... -2 %).
+// headline kernel (short of registers: longer live ranges cost it 0.7 %); parts 1-5 with -amdgpu-sched-strategy=max-ilp (birdie +3.9 %, config 4 +1.4 %,
+// headline +0.2 %; max-memory-clause: -0.6 ... -2 %).  (Parts 4 and 5: the two decomposed shapes, on their own for the
+// build's wall time -- 195 s for the slowest unit with four parts.)
 constexpr int shape_part(int index) {
     constexpr int table[] = {0 /* diode clipper */, 1 /* superover, fixed pots */, 2 /* superover, pots as inputs */,
                              0 /* birdie, fixed vol */, 1 /* birdie, vol as input */, 2 /* linear */, 3 /* generic small */,
-                             3 /* generic medium */, 3 /* generic large */, 2 /* decomposed small */, 1 /* decomposed medium */,
+                             3 /* generic medium */, 3 /* generic large */, 5 /* decomposed small */, 4 /* decomposed medium */,
                              0 /* superover, pots as inputs, condensed: +0.7 % with the default scheduler (registers) */};
     return index < (int)(sizeof(table) / sizeof(table[0])) ? table[index] : index % ACME_NPARTS;
 }
@@ -134,5 +135,7 @@ bool acme_shape_fns_part0(int index, ShapeFns *out);
 bool acme_shape_fns_part1(int index, ShapeFns *out);
 bool acme_shape_fns_part2(int index, ShapeFns *out);
 bool acme_shape_fns_part3(int index, ShapeFns *out);
+bool acme_shape_fns_part4(int index, ShapeFns *out);
+bool acme_shape_fns_part5(int index, ShapeFns *out);
 
 }  // namespace acme
