@@ -1966,20 +1966,14 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
         if (cnt > S::CH) cnt = S::CH;
         if constexpr (MODE == MODE_RUN_STREAM) {
             // streamed host run: the tile may still be on its way into HBM -- wait for the host's word that it has
-            // landed (a wave gets ahead of the copy engine only at the very start of a run), then read it past the
-            // caches (the copy engine wrote it after this kernel's launch)
+            // landed (a wave gets ahead of the copy engine only at the very start of a run).  The loads below are
+            // ordinary ones: the launcher lays the staging buffer out so that no cache line holds both samples that
+            // have landed and samples still to come (rows on 128-byte boundaries, chunks of whole lines), and nothing
+            // reads a sample before the word covers it; the acquire orders them after the word all the same.
             if (u_seen < n0 + cnt) {
                 while ((u_seen = wv::load_system(A.u_ready)) < n0 + cnt) wv::nap();
-                wv::acquire_system();      // (drops what the caches hold: a line may straddle the end of what had landed before)
+                wv::acquire_system();
             }
-#ifdef ACME_STREAM_UNCACHED
-            sfor<0, NU>([&](auto ic) ACME_LAMBDA {
-                constexpr int i = decltype(ic)::value;
-                int e = lig + GROUP * i;
-                upre[i] = (valid && e < (int)cnt * nu_io) ? wv::load_system(&ug[e]) : 0.0;
-            });
-            return;
-#endif
         }
         sfor<0, NU>([&](auto ic) ACME_LAMBDA {
             constexpr int i = decltype(ic)::value;

@@ -372,9 +372,8 @@ ACME_DEV void st2(double *p, double lo, double hi) {
 // the FMAs that consume them: a dependent dpp->fma pair costs ~17 cycles, batched ~9)
 ACME_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // streamed host runs (KArgs::u_ready): a counter the HOST advances while the kernel runs, and data a copy engine has
-// written since the launch -- both read past the caches (system scope)
+// written since the launch: the counter is read past the caches (system scope)
 ACME_DEV long long load_system(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-ACME_DEV double load_system(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 ACME_DEV void acquire_system() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
 // (~25 us: 2 048 waves polling host memory over the bus must not get in the copy engine's way)
 ACME_DEV void nap() { for (int k = 0; k < 8; ++k) __builtin_amdgcn_s_sleep(127); }

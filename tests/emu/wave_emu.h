@@ -254,7 +254,6 @@ ACME_DEV void touch(double) {}
 ACME_DEV int opaque(int v) { return v; }
 // (streamed host runs: the emulator launches synchronously, the host has copied everything before)
 ACME_DEV long long load_system(const long long *p) { return *p; }
-ACME_DEV double load_system(const double *p) { return *p; }
 ACME_DEV void acquire_system() {}
 ACME_DEV void nap() {}
 ACME_DEV unsigned long long pin(unsigned long long m) { return m; }
