@@ -120,15 +120,14 @@ template <class S> static ShapeFns make_shape_fns() {
 constexpr int ACME_NPARTS = 6;
 // Which part a shape lives in.  Not only for build time: the parts are compiled with different instruction
 // schedulers (__graft_entry__.py: HIP_UNIT_FLAGS).  Part 0 -- the smallest models, whose lane-per-instance kernels
-// prefer the compiler's default scheduler (the diode clipper sweep loses 1.2 % with max-ilp) -- and the condensed
-// headline kernel (short of registers: longer live ranges cost it 0.7 %); parts 1-5 with -amdgpu-sched-strategy=max-ilp (birdie +3.9 %, config 4 +1.4 %,
+// prefer the compiler's default scheduler (the diode clipper sweep loses 1.2 % with max-ilp); parts 1-5 with -amdgpu-sched-strategy=max-ilp (birdie +3.9 %, config 4 +1.4 %,
 // headline +0.2 %; max-memory-clause: -0.6 ... -2 %).  (Parts 4 and 5: the two decomposed shapes, on their own for the
 // build's wall time -- 195 s for the slowest unit with four parts.)
 constexpr int shape_part(int index) {
     constexpr int table[] = {0 /* diode clipper */, 1 /* superover, fixed pots */, 2 /* superover, pots as inputs */,
                              0 /* birdie, fixed vol */, 1 /* birdie, vol as input */, 2 /* linear */, 3 /* generic small */,
                              3 /* generic medium */, 3 /* generic large */, 5 /* decomposed small */, 4 /* decomposed medium */,
-                             0 /* superover, pots as inputs, condensed: +0.7 % with the default scheduler (registers) */};
+                             2 /* superover, pots as inputs, condensed: max-ilp +0.6 % (the default scheduler was +0.7 % for the first condensed kernel) */};
     return index < (int)(sizeof(table) / sizeof(table[0])) ? table[index] : index % ACME_NPARTS;
 }
 bool acme_shape_fns_part0(int index, ShapeFns *out);
