@@ -124,9 +124,14 @@ static inline int copy2d_h2d_async(void *d, size_t dpitch, const void *s, size_t
 static inline int copy2d_d2h_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, stream_t st) {
     return (int)hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToHost, st);
 }
-static inline int host_register(void *p, size_t n) { return (int)hipHostRegister(p, n, hipHostRegisterDefault); }
-static inline int host_unregister(void *p) { return (int)hipHostUnregister(p); }
-static inline int host_device_pointer(void **d, void *h) { return (int)hipHostGetDevicePointer(d, h, 0); }
+// (the callers tolerate a failure of these three -- memory that cannot be locked, a range the caller has freed -- and
+// go on with another path: the runtime's sticky error record must not outlive the decision)
+static inline int tolerated(hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return (int)e; }
+static inline int host_register(void *p, size_t n) { return tolerated(hipHostRegister(p, n, hipHostRegisterDefault)); }
+static inline int host_unregister(void *p) { return tolerated(hipHostUnregister(p)); }
+static inline int host_device_pointer(void **d, void *h) { return tolerated(hipHostGetDevicePointer(d, h, 0)); }
+static inline int dmalloc_try(void **p, size_t n) { return tolerated(hipMalloc(p, n ? n : 8)); }
+static inline int stream_wait_event(stream_t st, event_t e) { return (int)hipStreamWaitEvent(st, e, 0); }
 static inline int stream_create_nonblocking(stream_t *st) { return (int)hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
 static inline bool stream_idle(stream_t st) { return hipStreamQuery(st) == hipSuccess; }
 static inline int stream_destroy(stream_t st) { return st ? (int)hipStreamDestroy(st) : 0; }
@@ -138,14 +143,12 @@ static inline int event_record(event_t e, stream_t st) { return (int)hipEventRec
 static inline int event_sync(event_t e) { return (int)hipEventSynchronize(e); }
 static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)hipEventElapsedTime(ms, a, b); }
 static inline int launch_generic(const GArgs &A, stream_t st) {
-    hipLaunchKernelGGL(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
-    return (int)hipGetLastError();
+    return ACME_LAUNCH(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
 }
 static inline int launch_balance(const BalArgs &A, stream_t st) {
     const unsigned g = (unsigned)((A.nu + 255) / 256);
-    hipLaunchKernelGGL(acme_balance_weight_kernel, dim3(g), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(acme_balance_place_kernel, dim3(g), dim3(256), 0, st, A);
-    return (int)hipGetLastError();
+    const int rc = ACME_LAUNCH(acme_balance_weight_kernel, dim3(g), dim3(256), 0, st, A);
+    return rc ? rc : ACME_LAUNCH(acme_balance_place_kernel, dim3(g), dim3(256), 0, st, A);
 }
 // a word of host memory the device can read while a kernel runs (streamed host runs: KArgs::u_ready)
 static inline int flag_alloc(long long **h, const long long **d) {

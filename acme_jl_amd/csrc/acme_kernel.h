@@ -123,6 +123,16 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %; the big one lost 1.5 % in round 2
     // and gains 1.6 % now that the run kernel's rare paths are laid out of line (round 3)
     static constexpr bool SOLVE_SPLIT = true;
+    // The homotopy solver's direct attempt as the FIRST PASS of its bisection loop -- one inlined copy of the whole solver
+    // stack in the kernel instead of two (round 3 peeled the direct attempt out of the loop: +1.2 ... +12.6 % on kernels
+    // with registers to spare).  The condensed kernel has none: with the second copy its run kernel spilled 414 vector
+    // registers around the rare paths (428 B of scratch per lane), with one copy 39 (128 B) -- 292.3 -> 275.5 ms per step
+    // on the headline, bit-identical (round 5, EXPERIMENTS.md).
+#ifdef ACME_EXP_ONELOOP
+    static constexpr bool ONELOOP = true;
+#else
+    static constexpr bool ONELOOP = NL_ > 0;
+#endif
     // a launch's iteration total / maximum accumulated in registers by every lane instead of by LDS atomics
     // under a one-lane EXEC: birdie +3.0 %, fixed-pot superover and headline +-0 (the big shape has no
     // registers to spare and keeps the atomics)
@@ -2112,6 +2122,20 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     target = sel(need, pa, target);
                     return need ? (nh | 1) : (nh & ~1);
                 };
+                if constexpr (S::ONELOOP) {
+                // ONE copy of the solver: the direct attempt is the first pass of the homotopy loop
+                do {
+                    const bool need = (hf & 1) != 0;
+                    int its;
+                    const bool c = cached_solve(target, need, its);
+                    its_sample += need ? its : 0;
+                    int nh = need ? ((hf & ~2) | (c ? 2 : 0)) : hf;
+                    if (ACME_USUAL(A.solver == SOLVER_SIMPLE || !wv::ballot(need && !(mode == 0 && c)))) nh &= ~1;
+                    else nh = hstep(need, c, nh);
+                    hf = wv::keepi(nh);
+                    ACME_T(TB_HOMO);
+                } while (ACME_RARE(wv::ballot((hf & 1) != 0)));
+                } else {
                 {
                     const bool need = alive;
                     int its;
@@ -2136,6 +2160,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     else nh = hstep(need, c, nh);
                     hf = wv::keepi(nh);
                     ACME_T(TB_HOMO);
+                }
                 }
                 const bool conv = (hf & 2) != 0;
                 zs[s] = alive ? z : 0.0;

@@ -47,6 +47,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
     lane_main<S>(A, acme_lds);
 }
 
+// A launch's status.  hipGetLastError() returns -- and clears -- the last error ANY earlier call on this thread recorded
+// (a page-locking that was refused, an unregister of memory the caller had already freed: tolerated failures of the
+// host-buffer path), so the record is cleared before the launch: what is read after it is the launch's own.
+#define ACME_LAUNCH(...) ({ (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); (int)hipGetLastError(); })
+
 // the three 16-lane kernels of one shape in one placement (LDS / LOW): entry points for
 // hipFuncSetAttribute and launchers
 struct KernelFns {
@@ -58,20 +63,16 @@ struct KernelFns {
 };
 
 template <class S, bool LOW> static int launch_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((acme_run_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-    return (int)hipGetLastError();
+    return ACME_LAUNCH((acme_run_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
 }
 template <class S, bool LOW> static int launch_stream_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((acme_run_stream_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-    return (int)hipGetLastError();
+    return ACME_LAUNCH((acme_run_stream_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
 }
 template <class S, bool LOW> static int launch_jac_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((acme_jac_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-    return (int)hipGetLastError();
+    return ACME_LAUNCH((acme_jac_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
 }
 template <class S, bool LOW> static int launch_solve_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((acme_solve_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
-    return (int)hipGetLastError();
+    return ACME_LAUNCH((acme_solve_kernel<S, LOW>), dim3(grid), dim3(WAVES_PER_BLOCK * 64), lds_bytes, st, A);
 }
 template <class S, bool LOW> static KernelFns make_fns() {
     KernelFns f;
@@ -99,8 +100,7 @@ struct ShapeFns {
 };
 template <class S> static int launch_lane_shape(const KArgs &A, unsigned grid, size_t lds_bytes, hipStream_t st) {
     if constexpr (LaneShape<S>::supported) {
-        hipLaunchKernelGGL(acme_lane_kernel<S>, dim3(grid), dim3(LANE_BLOCK), lds_bytes, st, A);
-        return (int)hipGetLastError();
+        return ACME_LAUNCH(acme_lane_kernel<S>, dim3(grid), dim3(LANE_BLOCK), lds_bytes, st, A);
     } else {
         return (int)hipErrorInvalidValue;
     }
@@ -127,7 +127,7 @@ constexpr int shape_part(int index) {
     constexpr int table[] = {0 /* diode clipper */, 1 /* superover, fixed pots */, 2 /* superover, pots as inputs */,
                              0 /* birdie, fixed vol */, 1 /* birdie, vol as input */, 2 /* linear */, 3 /* generic small */,
                              3 /* generic medium */, 3 /* generic large */, 5 /* decomposed small */, 4 /* decomposed medium */,
-                             2 /* superover, pots as inputs, condensed: max-ilp +0.6 % (the default scheduler was +0.7 % for the first condensed kernel) */};
+                             0 /* superover, pots as inputs, condensed -- the headline kernel: the default scheduler again (round 5, one solver copy: 275.1 ms against 278.6 with max-ilp; round 4's two-copy kernel gained 0.6 % with max-ilp) */};
     return index < (int)(sizeof(table) / sizeof(table[0])) ? table[index] : index % ACME_NPARTS;
 }
 bool acme_shape_fns_part0(int index, ShapeFns *out);

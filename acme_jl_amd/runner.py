@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape", "acme_model_kernel_variant",
     "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
-    "acme_batch_run_async", "acme_batch_wait", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
+    "acme_batch_run_async", "acme_batch_wait", "acme_batch_set_host_retention", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
     "acme_batch_set_balance", "acme_batch_get_placement",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
     "acme_batch_set_resabstol", "acme_batch_get_state", "acme_batch_set_state",
@@ -118,6 +118,7 @@ class Library:
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_run_async.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_wait.argtypes = [vp]
+        L.acme_batch_set_host_retention.argtypes = [vp, C.c_int]
         L.acme_batch_release_host_buffers.argtypes = [vp]
         L.acme_batch_set_isolation.argtypes = [vp, C.c_double]
         L.acme_batch_set_balance.argtypes = [vp, C.c_int]
@@ -269,14 +270,32 @@ class ModelRunner:
         self.lib.check(self.lib.L.acme_batch_get_placement(self.h, _ip(out), None))
         return out
 
+    def set_host_retention(self, keep=True):
+        """``acme_batch_set_host_retention``: promise that the host arrays handed to ``run_async`` / ``run(layout="abi")``
+        stay allocated until others are passed, ``release_host_buffers()`` is called or the runner goes -- they are then
+        page-locked once and runs are streamed at the device-resident rate.  Off by default: ``run`` works on per-call
+        temporaries, which must never stay registered."""
+        self.lib.check(self.lib.L.acme_batch_set_host_retention(self.h, 1 if keep else 0))
+        self._retain = bool(keep)
+        if not keep:
+            self._held = None
+
     def release_host_buffers(self):
         """Un-page-lock the arrays of the last host-buffer run (``acme_batch_release_host_buffers``)."""
         self.lib.check(self.lib.L.acme_batch_release_host_buffers(self.h))
+        self._held = None
+
+    def _hold(self, *arrays):
+        # a retaining runner keeps the arrays it handed to the library alive for as long as they may be page-locked:
+        # until the next call's arrays replace them, release_host_buffers() or the batch's destruction
+        if getattr(self, "_retain", False):
+            self._held = arrays
 
     def __del__(self):
         if getattr(self, "h", None):
-            self.lib.L.acme_batch_destroy(self.h)
+            self.lib.L.acme_batch_destroy(self.h)       # (un-page-locks whatever is held: before the arrays go)
             self.h = None
+        self._held = None
 
     # ---- per-instance matrices ----------------------------------------------------------
     def set_models(self, first, models, chunk=1024):
@@ -335,6 +354,7 @@ class ModelRunner:
                 y = np.empty((self.n, T, m.ny), dtype=np.float64)
             ub = np.ascontiguousarray(u)
             self.lib.check(self.lib.L.acme_batch_run(self.h, ub.ctypes.data, y.ctypes.data, T, ACME_MEM_HOST, None))
+            self._hold(ub, y)
             if check:
                 self.check()
             return y
@@ -356,6 +376,7 @@ class ModelRunner:
         yb = np.empty((self.n, T, m.ny), dtype=np.float64)
         self.lib.check(self.lib.L.acme_batch_run(
             self.h, ub.ctypes.data, yb.ctypes.data, T, ACME_MEM_HOST, None))
+        self._hold(ub, yb)
         out = np.transpose(yb, (0, 2, 1))
         if y is not None:
             (y[None] if single else y)[...] = out
@@ -377,6 +398,7 @@ class ModelRunner:
                 raise DimensionMismatch(f"{what} must have shape ({self.n}, T, {cols})")
         self._check_io(u.shape[2], y.shape[2], u.shape[1], y.shape[1])
         self._inflight = (u, y)
+        self._hold(u, y)
         self.lib.check(self.lib.L.acme_batch_run_async(self.h, u.ctypes.data, y.ctypes.data, u.shape[1],
                                                        ACME_MEM_HOST, None))
 

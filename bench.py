@@ -328,6 +328,12 @@ def host_buffer_leg(runner, u, N, T, model):
         return time.perf_counter() - t0
     out = {"bytes_in": int(uh.nbytes), "bytes_out": int(yh.nbytes)}
     os.environ.pop("ACME_HOST_REGISTER", None)
+    # what a caller gets who promises nothing (the default; what ModelRunner.run and Julia's run! on fresh arrays do):
+    # ONE call, nothing page-locked, nothing of the arrays kept
+    t_oneshot = call(uh, yh)
+    out.update(one_shot_ms=1e3 * t_oneshot, one_shot_value=N * T / t_oneshot)
+    # ... and a caller who reuses its arrays and says so (acme_batch_set_host_retention)
+    runner.set_host_retention(True)
     t_first = call(uh, yh)
     ts = [call(uh, yh) for _ in range(2)]
     out.update(first_call_ms=1e3 * t_first, steady_ms=1e3 * min(ts), steady_value=N * T / min(ts),
@@ -348,6 +354,7 @@ def host_buffer_leg(runner, u, N, T, model):
             finally:
                 os.environ.pop("ACME_HOST_SLICES", None)
     runner.release_host_buffers()
+    runner.set_host_retention(False)
     os.environ["ACME_HOST_REGISTER"] = "0"
     try:
         t_page = min(call(uh, yh) for _ in range(2))
@@ -356,8 +363,11 @@ def host_buffer_leg(runner, u, N, T, model):
     out.update(inplace_ms=1e3 * extra["inplace"], inplace_value=N * T / extra["inplace"],
                staged_ms=1e3 * extra["staged"], staged_value=N * T / extra["staged"],
                pageable_ms=1e3 * t_page, pageable_value=N * T / t_page,
-               note="acme_batch_run(ACME_MEM_HOST) on the timed batch, continuing the signal.  first call: page-locks the "
-                    "caller's arrays; steady: the same arrays again -- the default, STREAMED pipeline: one launch over the whole "
+               note="acme_batch_run(ACME_MEM_HOST) on the timed batch, continuing the signal.  one_shot: the default -- a single "
+                    "call on arrays the library may not keep anything of (pageable memory, 24 time slices staged through HBM "
+                    "with the copies overlapping the kernel).  The rest with acme_batch_set_host_retention (the caller keeps "
+                    "its arrays alive and reuses them).  first call: page-locks the "
+                    "caller's arrays; steady: the same arrays again -- the STREAMED pipeline: one launch over the whole "
                     "run, y written to the locked host array by the kernel itself, u copied into an HBM staging buffer by "
                     "the copy engine 128 samples of every row at a time while the kernel runs (a wave that gets ahead of "
                     "the copy waits: KArgs::u_ready); inplace (ACME_HOST_SLICES=1): one launch, u and y both in place over "

@@ -141,22 +141,29 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
                             const acme_model *const *models);
 
 /* run!(runner, y, u): advance every instance by T samples (src/ACME.jl:650-664).
- * mem = ACME_MEM_HOST: u/y are host buffers.  Runs of 4096+ samples are STREAMED: one launch; the kernel writes
- *   y to the (page-locked, mapped) array itself and reads u from an HBM staging buffer the copy engine fills
- *   while the kernel runs (waves that get ahead of the copy wait) -- the device-resident rate.  With a progress
- *   callback installed, for memory that cannot be page-locked, and for the lane-per-instance and generic
- *   kernels: time slices whose copies overlap the kernel.  The call returns when y is complete;
+ * mem = ACME_MEM_HOST: u/y are host buffers, copied in time slices that overlap the kernel.  On a batch with
+ *   acme_batch_set_host_retention (arrays page-locked and mapped), runs of 4096+ samples are STREAMED: one launch;
+ *   the kernel writes y to the caller's array itself and reads u from an HBM staging buffer the copy engine fills
+ *   while the kernel runs (waves that get ahead of the copy wait) -- the device-resident rate; not with a progress
+ *   callback installed, for memory that cannot be page-locked, for batches of more blocks than the chip holds at
+ *   once, nor for the lane-per-instance and generic kernels (time slices).  The call returns when y is complete;
  * mem = ACME_MEM_DEVICE: u/y are device pointers on the batch's device and `stream` is the
  * hipStream_t to launch on (NULL = default stream); the call is then asynchronous. */
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
                    void *stream);
-/* Host-buffer runs page-lock the caller's u and y for DMA (copies from pageable memory run at less than
- * half the bus rate, and page-locking costs about one copy): the last range of each direction stays
- * locked, so that a caller reusing its arrays across run! calls -- what the in-place run!(runner, y, u)
- * is for, src/ACME.jl:650-664 -- pays once.  The ranges are released when other arrays come, by
- * acme_batch_destroy, and by this call (before the caller frees or resizes its arrays while the batch
- * lives on).  Memory that cannot be locked is copied from as it is.  ACME_HOST_REGISTER=0 in the
- * environment disables the locking. */
+/* Host-buffer runs and page-locking.  By DEFAULT the library never keeps anything of the caller's arrays beyond the
+ * call: u and y are copied from / to ordinary (pageable) memory in time slices that overlap the kernel -- the right
+ * thing for one-shot calls and for wrappers whose arrays are per-call temporaries or garbage-collected (locking
+ * 14.4 GB costs more than running them: headline 0.39 s this way, 0.70 s locked and streamed).
+ * keep != 0: the caller PROMISES that the arrays it passes stay allocated until it passes others, calls
+ * acme_batch_release_host_buffers or destroys the batch.  The library then page-locks and maps them
+ * (hipHostRegister) on first use and keeps the last range of each direction locked: runs of 4096+ samples are
+ * STREAMED (see acme_batch_run) at the device-resident rate -- what the in-place run!(runner, y, u) with reused
+ * arrays is for (src/ACME.jl:650-664).  Memory that cannot be locked is copied from as it is.
+ * ACME_HOST_REGISTER=0 in the environment disables the locking altogether. */
+int acme_batch_set_host_retention(acme_batch *b, int keep);
+/* un-page-lock what a retaining batch (above) holds: before the caller frees or resizes its arrays while the
+ * batch lives on.  Idempotent. */
 int acme_batch_release_host_buffers(acme_batch *b);
 /* @showprogress of run!(runner, y, u) (src/ACME.jl:587-604,653): `fn(user, samples_done, samples_total)`
  * is called on the calling thread (the worker thread of an asynchronous run) after every time slice of a

@@ -34,7 +34,7 @@ import ProgressMeter
 import ACME: run!, solve, hasconverged, needediterations, set_resabstol!,
              get_extrapolation_origin, set_extrapolation_origin, get_extrapolation_jacobian
 
-export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, release_host_buffers!, set_isolation!, set_balance!
+export BatchRunner, MultiBatchRunner, GPUBatchSolver, element_table, retain_host_buffers!, release_host_buffers!, set_isolation!, set_balance!
 
 const lib = get(ENV, "ACME_HIP_LIB", "libacme_hip.so")
 
@@ -233,10 +233,22 @@ function BatchRunner(model::DiscreteModel, n::Integer; device::Integer=-1,
 end
 
 """
+    retain_host_buffers!(runner, keep=true)
+
+By default `run!` leaves nothing of `u` / `y` registered with the GPU runtime once it returns (they are ordinary,
+garbage-collected arrays: a registration must never outlive them).  `retain_host_buffers!(runner)` is the caller's
+promise to keep the arrays it passes alive -- reuse them across `run!(runner, y, u)` calls, hold references -- until it
+passes others, calls `release_host_buffers!` or drops the runner: they are then page-locked once and runs are streamed
+at the device-resident rate (`acme_batch_set_host_retention`, `include/acme_hip.h`).
+"""
+retain_host_buffers!(r::BatchRunner, keep::Bool=true) =
+    (check(ccall((:acme_batch_set_host_retention, lib), Cint, (Ptr{Cvoid}, Cint), r.h, keep ? 1 : 0)); r)
+
+"""
     release_host_buffers!(runner)
 
-`run!` page-locks `u` and `y` for DMA and keeps the last pair locked (re-used arrays pay once); call this before
-freeing or resizing them while the runner lives on.
+Un-page-lock what a retaining runner (`retain_host_buffers!`) holds: before freeing or resizing the arrays while the
+runner lives on.
 """
 release_host_buffers!(r::BatchRunner) =
     (check(ccall((:acme_batch_release_host_buffers, lib), Cint, (Ptr{Cvoid},), r.h)); r)

@@ -216,6 +216,8 @@ static inline int get_device(int *d) { *d = 0; return 0; }
 static inline int set_max_lds(const void *, int) { return 0; }
 static inline int dmalloc(void **p, size_t n) { *p = malloc(n ? n : 8); return *p ? 0 : 1; }
 static inline int dfree(void *p) { free(p); return 0; }
+static inline int dmalloc_try(void **p, size_t n) { return dmalloc(p, n); }
+static inline int stream_wait_event(void *, struct Ev *) { return 0; }
 static inline int copy_h2d(void *d, const void *s, size_t n) { memcpy(d, s, n); return 0; }
 static inline int copy_d2h(void *d, const void *s, size_t n) { memcpy(d, s, n); return 0; }
 static inline int copy_h2d_async(void *d, const void *s, size_t n, stream_t) { memcpy(d, s, n); return 0; }

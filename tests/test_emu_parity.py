@@ -679,6 +679,7 @@ def test_emulated_host_buffer_pipelines_agree(emu_lib, monkeypatch):
         seen = []
         # (a progress callback asks for time slices: the streamed pipeline is one launch)
         r = ModelRunner(m, N, lib=emu_lib, showprogress=False if name == "default" else lambda done, total: seen.append((done, total)))
+        r.set_host_retention(True)                 # (these pipelines work on page-locked, mapped arrays: the runner holds them)
         y1 = r.run(u)
         y2 = r.run(u[:, :, :4200])                 # (a second call on a sub-range of the same arrays' shape)
         out[name] = (y1, y2, [d for d, _ in seen])
@@ -692,6 +693,12 @@ def test_emulated_host_buffer_pipelines_agree(emu_lib, monkeypatch):
     assert out["3 slices"][2][:3] == [1504, 3008, 4500]
     yref, _ = oracle_run(m, u)
     assert_close(out["default"][0], yref, rtol=1e-12)
+    # the default: nothing of the caller's arrays is kept (acme_batch_set_host_retention off) -- the staged pipeline from
+    # ordinary memory, same bits; no range stays "page-locked" behind the call
+    r = ModelRunner(m, N, lib=emu_lib)
+    y1 = r.run(u)
+    assert np.array_equal(y1, out["default"][0])
+    assert getattr(r, "_held", None) is None
 
 
 def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):

@@ -691,7 +691,7 @@ def test_host_buffer_paths_agree_bit_for_bit(hip_lib, monkeypatch):
     ub = np.ascontiguousarray(np.transpose(u, (0, 2, 1)))        # [N][T][nu]: the ABI's layout (> 1 MB: page-locked)
     dp = C.POINTER(C.c_double)
     outs = {}
-    for mode, env in (("default", {}), ("sliced", {}), ("in place", {"ACME_HOST_SLICES": "1"}), ("3 slices", {"ACME_HOST_SLICES": "3"}),
+    for mode, env in (("one shot", {}), ("default", {}), ("sliced", {}), ("in place", {"ACME_HOST_SLICES": "1"}), ("3 slices", {"ACME_HOST_SLICES": "3"}),
                       ("streamed, 16-sample chunks", {"ACME_HOST_STREAM_CHUNK": "16"}),
                       ("staged", {"ACME_HOST_ZEROCOPY": "0"}), ("pageable", {"ACME_HOST_REGISTER": "0"})):
         for k in ("ACME_HOST_ZEROCOPY", "ACME_HOST_REGISTER", "ACME_HOST_SLICES", "ACME_HOST_STREAM_CHUNK"):
@@ -704,9 +704,13 @@ def test_host_buffer_paths_agree_bit_for_bit(hip_lib, monkeypatch):
         streamed = mode == "default" or mode.startswith("streamed")
         cb = False if streamed else (lambda d, t: seen.append((d, t)))
         r = ModelRunner(m, N, lib=hip_lib, showprogress=cb)
+        # "one shot": what a caller gets who promises nothing about its arrays (the default) -- nothing page-locked;
+        # every other mode: acme_batch_set_host_retention (ub / yb outlive the runners here)
+        r.set_host_retention(mode != "one shot")
         yb = np.full((N, T, m.ny), np.nan)
         for _ in range(2):       # (the second call finds the arrays page-locked)
             r2 = ModelRunner(m, N, lib=hip_lib, showprogress=cb)
+            r2.set_host_retention(mode != "one shot")
             r2.lib.check(r2.lib.L.acme_batch_run(r2.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
             r2.release_host_buffers()
         r.lib.check(r.lib.L.acme_batch_run(r.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
@@ -772,6 +776,7 @@ def test_streamed_host_runs_see_fresh_inputs(hip_lib):
     ub = np.ascontiguousarray(np.transpose(u, (0, 2, 1)))             # [N][K T][nu]
     dp = C.POINTER(C.c_double)
     r = ModelRunner(m, N, lib=hip_lib)
+    r.set_host_retention(True)
     uk, yk = np.empty((N, T, m.nu)), np.empty((N, T, m.ny))            # the caller's arrays, reused (page-locked once)
     ys = []
     for k in range(K):
@@ -785,3 +790,46 @@ def test_streamed_host_runs_see_fresh_inputs(hip_lib):
         assert np.array_equal(ys[k], yd[:, k * T:(k + 1) * T, :]), k
     for a, b in zip(r.get_state(), ref.get_state()):
         assert np.array_equal(a, b)
+
+
+def test_host_arrays_may_be_freed_after_any_call(hip_lib):
+    """nothing of a caller's arrays may stay page-locked behind a call unless the caller asked for it.  Large
+    per-call temporaries (> 1 MB: munmap'd on free, the next one usually lands at the same address) through the default
+    path, freed between the calls; then a RETAINING runner whose arrays are freed before it is (a contract violation the
+    library cannot detect -- but the failing un-registration must not poison the launches of other batches: the sticky
+    error record of the HIP runtime is cleared behind every tolerated failure)."""
+    import ctypes as C
+    import gc
+    import torch
+    from acme_jl_amd.runner import ACME_MEM_HOST, ModelRunner
+    m = load("superover_var")
+    N, T = 64, 4501
+    u = sweep_inputs("superover_var", N, 3 * T, seed=5)
+    dp = C.POINTER(C.c_double)
+    r = ModelRunner(m, N, lib=hip_lib)
+    ys = []
+    for k in range(3):
+        ub = np.ascontiguousarray(np.transpose(u[:, :, k * T:(k + 1) * T], (0, 2, 1)))      # 9 MB, fresh every call
+        yb = np.empty((N, T, m.ny))
+        r.lib.check(r.lib.L.acme_batch_run(r.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
+        ys.append(yb.copy())
+        del ub, yb
+        gc.collect()
+    ref = ModelRunner(m, N, lib=hip_lib)
+    yd = ref.run_torch(torch.from_numpy(np.ascontiguousarray(np.transpose(u, (0, 2, 1)))).cuda()).cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(ys[k], yd[:, k * T:(k + 1) * T, :]), k
+    # a retaining runner outliving its arrays
+    r2 = ModelRunner(m, N, lib=hip_lib)
+    r2.lib.check(r2.lib.L.acme_batch_set_host_retention(r2.h, 1))        # (the raw ABI: ModelRunner would hold the arrays)
+    ub = np.ascontiguousarray(np.transpose(u[:, :, :T], (0, 2, 1)))
+    yb = np.empty((N, T, m.ny))
+    r2.lib.check(r2.lib.L.acme_batch_run(r2.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
+    assert np.array_equal(yb, yd[:, :T, :])
+    del ub, yb
+    gc.collect()
+    del r2                                      # un-registers ranges that are gone: tolerated
+    gc.collect()
+    r3 = ModelRunner(m, N, lib=hip_lib)
+    y3 = r3.run(u[:, :, :100])                  # a launch right behind the failed un-registration
+    assert np.array_equal(np.transpose(y3, (0, 2, 1)), yd[:, :100, :])
