@@ -36,9 +36,11 @@ struct GenHeader {
     int o_a, o_b, o_c, o_x0, o_dy, o_ey, o_fy, o_y0;
     int image_total;
     int nnmax, nqmax, npmax;
+    int ldf;                 // leading dimension of the nnmax x nnmax factor matrices in the workspace (>= nnmax; the lane-per-instance
+                             // kernel stores them column-major and packed, the cooperative one row-major with this row pitch)
     int has_bjt;
     // workspace (doubles per instance): x | xnew | zall | per sub-problem origins | scratch of one solve
-    int w_x, w_xn, w_z, w_p, w_pa, w_sp, w_zz, w_res, w_dz, w_lu, w_piv, w_jp, w_q, w_pf, w_tv, w_tmp;
+    int w_x, w_xn, w_z, w_p, w_pa, w_sp, w_zz, w_res, w_dz, w_lu, w_piv, w_jp, w_q, w_pf, w_tv, w_tmp, w_u;
     int ws_total;
     int state_total;         // doubles per instance in the state array: x | last_p of every sub | last_z of every sub
     int cache_total;         // doubles per instance of solution caches: per sub cp[np][CACHE] | count, head | cz[CACHE][nn]
@@ -67,6 +69,8 @@ struct GArgs {
     int *conv_out, *iters_out;
     double *jac_out;         // GEN_JAC:   [n_inst][np_sub][nn_sub]
     int solve_sub;
+    int coop_imgl;           // acme_coop.h: the (shared) model image is staged in LDS
+    int coop_gpw;            // acme_coop.h: instances per wave (4, 2 or 1: what the LDS of a compute unit holds most of)
 };
 
 #ifdef ACME_DEV

@@ -18,6 +18,7 @@
 #include "../../include/acme_hip.h"
 #include "acme_kernels.h"
 #include "acme_pack.h"
+#include "acme_coop.h"
 
 using namespace acme;
 
@@ -74,6 +75,12 @@ static const std::vector<KernelEntry> &kernel_table() {
 __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
     const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
     if (i < A.n_inst) gen_main(A, i);
+}
+
+// the mid-size kernel (acme_coop.h): one wave per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
+template <bool IMGL> __global__ __launch_bounds__(64) void acme_coop_kernel(GArgs A) {
+    extern __shared__ double acme_lds[];
+    coop_main<IMGL>(A, acme_lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // placement of the waves by their measured cost (acme_balance.h): one thread per wave
@@ -144,6 +151,19 @@ static inline int event_sync(event_t e) { return (int)hipEventSynchronize(e); }
 static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)hipEventElapsedTime(ms, a, b); }
 static inline int launch_generic(const GArgs &A, stream_t st) {
     return ACME_LAUNCH(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
+}
+static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t st) {
+    static size_t allowed[2] = {0, 0};       // (dynamic LDS beyond 64 KB has to be asked for, once per size)
+    const bool imgl = A.coop_imgl != 0;
+    const void *fn = imgl ? (const void *)acme_coop_kernel<true> : (const void *)acme_coop_kernel<false>;
+    if (lds_bytes > allowed[imgl]) {
+        const int rc = set_max_lds(fn, (int)lds_bytes);
+        if (rc != 0) return rc;
+        allowed[imgl] = lds_bytes;
+    }
+    const dim3 grid((unsigned)((A.n_inst + A.coop_gpw - 1) / A.coop_gpw));
+    if (imgl) return ACME_LAUNCH(acme_coop_kernel<true>, grid, dim3(64), lds_bytes, st, A);
+    return ACME_LAUNCH(acme_coop_kernel<false>, grid, dim3(64), lds_bytes, st, A);
 }
 static inline int launch_balance(const BalArgs &A, stream_t st) {
     const unsigned g = (unsigned)((A.nu + 255) / 256);

@@ -686,16 +686,21 @@ inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err)
     }
     H.has_bjt = dummy.has_bjt;
     // workspace
+    // (factor matrices: room for the cooperative kernel's row pitch -- at least 3 columns of slack for its 4-wide updates,
+    // and a pitch of 2 mod 4 doubles so that the 16 rows a DPP row of lanes touches in one LDS access fall into 16 distinct
+    // bank groups, acme_coop.h)
+    H.ldf = H.nnmax + 3;
+    while (H.ldf % 4 != 2) ++H.ldf;
     int w = 0;
     auto wt = [&](int n) { int at = w; w += n; return at; };
     H.w_x = wt(m.nx); H.w_xn = wt(m.nx); H.w_z = wt(nnt);
     for (int k = 0; k < H.nsub; ++k) {
         GenSub &g = H.sub[k];
-        g.w_lp = wt(g.np); g.w_lz = wt(g.nn); g.w_ljp = wt(g.nn * g.np); g.w_llu = wt(g.nn * g.nn); g.w_lpiv = wt(g.nn);
+        g.w_lp = wt(g.np); g.w_lz = wt(g.nn); g.w_ljp = wt(g.nn * g.np); g.w_llu = wt(g.nn * H.ldf); g.w_lpiv = wt(g.nn);
     }
     H.w_p = wt(H.npmax); H.w_pa = wt(H.npmax); H.w_sp = wt(H.npmax); H.w_zz = wt(H.nnmax); H.w_res = wt(H.nnmax);
-    H.w_dz = wt(H.nnmax); H.w_lu = wt(H.nnmax * H.nnmax); H.w_piv = wt(H.nnmax); H.w_jp = wt(H.nnmax * H.npmax);
-    H.w_q = wt(H.nqmax); H.w_pf = wt(H.nqmax); H.w_tv = wt(4 * H.nnmax); H.w_tmp = wt(H.nnmax);
+    H.w_dz = wt(H.nnmax); H.w_lu = wt(H.nnmax * H.ldf); H.w_piv = wt(H.nnmax); H.w_jp = wt(H.nnmax * H.npmax);
+    H.w_q = wt(H.nqmax); H.w_pf = wt(H.nqmax); H.w_tv = wt(4 * H.nnmax); H.w_tmp = wt(H.nnmax); H.w_u = wt(m.nu);
     H.ws_total = w > 0 ? w : 1;
     return true;
 }

@@ -199,6 +199,13 @@ class _ModelHandle:
         self.lib.check(self.lib.L.acme_model_kernel_variant(self.h, C.byref(nl), C.byref(gen)))
         return nl.value, bool(gen.value)
 
+    def kernel_family(self):
+        """"tuned" (an instantiated shape), "coop" (run-time-sized, one instance per 16 lanes, working arrays in LDS:
+        csrc/acme_coop.h) or "generic" (run-time-sized, one lane per instance: csrc/acme_generic.h)"""
+        gen = C.c_int(0)
+        self.lib.check(self.lib.L.acme_model_kernel_variant(self.h, None, C.byref(gen)))
+        return ("tuned", "generic", "coop")[gen.value]
+
     def __del__(self):
         if getattr(self, "h", None):
             self.lib.L.acme_model_destroy(self.h)
@@ -527,6 +534,9 @@ class ModelRunner:
 
     def kernel_variant(self):
         return self._mh.kernel_variant()
+
+    def kernel_family(self):
+        return self._mh.kernel_family()
 
 
 class MultiDeviceRunner:

@@ -95,17 +95,27 @@ def make_u(torch, dev, model, pots, amp, n, T, fs=FS):
     return u
 
 
-def pmc_record(workload, n, T):
-    """The committed rocprofv3 PMC passes of this exact workload (profiles/pmc_traffic.json, written
-    by tools/profile_gpu.sh: separate --pmc runs of this command), or None."""
+def pmc_record(workload, n, T, solver=None, kernel=None, kernel_ms=None):
+    """The committed rocprofv3 PMC passes of THIS run's configuration (profiles/pmc_traffic.json, written by
+    tools/profile_gpu.sh: separate --pmc runs of the same command), or None.  A record only counts if it was taken
+    on the same workload, size, solver stack and kernel variant, and -- when this run's kernel time is given -- if
+    the profiled launches lasted within 3 % of it: a stale number is worse than none."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             rec = json.load(fh)
     except OSError:
         return None
     for r in rec.get("runs", []):
-        if r.get("workload") == workload and r.get("instances") == n and r.get("samples") == T:
-            return r
+        if r.get("workload") != workload or r.get("instances") != n or r.get("samples") != T:
+            continue
+        if solver is not None and r.get("solver") != solver:
+            continue
+        if kernel is not None and r.get("kernel") != kernel:
+            continue
+        prof = r.get("kernel_avg_ms_profiled")
+        if kernel_ms is not None and (not prof or abs(prof - kernel_ms) > 0.03 * kernel_ms):
+            continue
+        return r
     return None
 
 
@@ -118,31 +128,37 @@ def kernel_name(runner):
     return name + (", condensed rows %d>>" % nl if nl else ">>")
 
 
-def pmc_traffic(workload, n, T):
-    """HBM bytes per launch from the PMC passes, or None if no pass for this exact workload is on
-    file.  Reads = 2 x FETCH_SIZE: gfx950 tallies this kernel's coalesced reads at half their size
-    (calibrated on the known byte count of the u stream)."""
-    r = pmc_record(workload, n, T)
+def pmc_traffic(r):
+    """HBM bytes per launch from the PMC passes (record r of pmc_record, or None).  Reads = 2 x FETCH_SIZE: gfx950
+    tallies this kernel's coalesced reads at half their size (calibrated on the known byte count of the u stream)."""
     if r is None:
         return None
     return 1024.0 * (2.0 * r["fetch_size_kb_per_launch"] + r["write_size_kb_per_launch"])
 
 
-def pmc_valu_issue_frac(workload, n, T, n_simd=1024, n_xcd=8):
+def pmc_valu_issue_frac(r, n_simd=1024, n_xcd=8):
     """Share of the chip's VALU issue slots the profiled launch used: SQ_INSTS_VALU wave-instructions
     against one 64-lane fp64 instruction per SIMD every 4 cycles (GRBM_GUI_ACTIVE sums the XCDs)."""
-    r = pmc_record(workload, n, T)
-    if r is None or "sq_insts_valu_per_launch" not in r:
+    if r is None or not r.get("sq_insts_valu_per_launch") or not r.get("grbm_gui_active_per_launch"):
         return None
     return r["sq_insts_valu_per_launch"] / (n_simd * r["grbm_gui_active_per_launch"] / n_xcd / 4.0)
 
 
-def pmc_lds_bank_conflict_frac(workload, n, T):
+def pmc_lds_bank_conflict_frac(r):
     """SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the profiled timed steps (north_star names the counter), or None."""
-    r = pmc_record(workload, n, T)
     if r is None or not r.get("sq_lds_idx_active_per_launch"):
         return None
     return r["sq_lds_bank_conflict_per_launch"] / r["sq_lds_idx_active_per_launch"]
+
+
+def pmc_fp64_executed_flops(r):
+    """fp64 operations the profiled launch EXECUTED: 64 lanes x (2 FMA + MUL + ADD + TRANS) wave-instructions
+    (SQ_INSTS_VALU_*_F64).  Lanes masked off by EXEC are counted (the counters tally wave-instructions): an upper
+    bound of the useful arithmetic, and the honest numerator for the FP64 pipe's utilisation."""
+    if r is None or r.get("sq_insts_valu_fma_f64_per_launch") is None:
+        return None
+    return 64.0 * (2.0 * r["sq_insts_valu_fma_f64_per_launch"] + (r.get("sq_insts_valu_mul_f64_per_launch") or 0.0)
+                   + (r.get("sq_insts_valu_add_f64_per_launch") or 0.0) + (r.get("sq_insts_valu_trans_f64_per_launch") or 0.0))
 
 
 def algorithmic_bytes(model, n, T):
@@ -313,6 +329,49 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     return out
 
 
+def other_workload_leg(workload, local_rank, dev, steps=2, warmup=2):
+    """One short steady-state measurement of another BASELINE configuration (config.other_workloads; never `value`):
+    the same procedure as the headline's timed steps -- fresh batch, `warmup` launches continuing into `steps` timed
+    ones -- at the configuration's own size and solver stack."""
+    import torch
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel, HomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    n = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(workload, 8192)
+    fs = 176400 if workload == "birdie_grid" else FS
+    T = fs
+    solver = HomotopySolver if workload == "birdie_grid" else CachingHomotopySolver
+    fixture, pots, amp = grid_inputs(workload, 0, 1, n, T)
+    model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
+    if workload == "superover_montecarlo":
+        batch = montecarlo_models(0, n, init_on_device={"device": local_rank})
+        batch.solver = solver
+        model = batch.model(0)
+        runner = ModelRunner(model, n, device=local_rank, models=batch)
+    else:
+        runner = ModelRunner(model, n, device=local_rank)
+    u = make_u(torch, dev, model, pots, amp, n, T, fs)
+    y = torch.empty((n, T, model.ny), dtype=torch.float64, device=dev)
+    for _ in range(warmup):
+        runner.run_torch(u, y)
+    torch.cuda.synchronize()
+    runner.reset_report()
+    runner.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.run_torch(u, y)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms_total, launches = runner.kernel_time()
+    ra = runner.report_arrays()
+    return {"workload": workload, "config": {"diodeclipper_sweep": 2, "superover_montecarlo": 4, "birdie_grid": 5}[workload],
+            "instances": n, "samples_per_step": T, "fs": fs, "solver": model.solver, "steps": steps, "warmup": warmup,
+            "value": n * T * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": ms_total / max(launches, 1),
+            "kernel": ("acme_lane_kernel<Shape<%d,%d,%d,%d,%d,%d>>" % runner.kernel_shape()) if workload == "diodeclipper_sweep"
+            and os.environ.get("ACME_LANE_KERNEL") != "0" else kernel_name(runner),
+            "newton_iters_per_sample": float(ra["iters_total"].sum()) / (n * T * steps), "n_warn": float(ra["n_warn"].sum()),
+            "y_abs_sum": float(torch.nan_to_num(y).abs().sum())}
+
+
 def host_buffer_leg(runner, u, N, T, model):
     """run! through host buffers (see main): instance*samples/s of the first call (page-locks u and y), of the
     following calls on the same arrays (steady state) and, on a second pair of arrays, from pageable memory."""
@@ -388,6 +447,8 @@ def main():
                          "config 2; superover_montecarlo = config 4 (per-instance model blocks); birdie_grid = "
                          "config 5 (176.4 kHz, 2048 instances per GPU, HomotopySolver unless --solver is given)")
     ap.add_argument("--instances", type=int, default=None, help="instances per GPU")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short steady-state legs of BASELINE configs 2, 4, 5 (config.other_workloads) that follow the headline")
     ap.add_argument("--samples", type=int, default=None, help="samples per step (default: 1 s of signal)")
     ap.add_argument("--solver", default=None, choices=["caching", "homotopy", "simple"],
                     help="caching = HomotopySolver{CachingSolver{SimpleSolver}}, the reference's default stack "
@@ -546,6 +607,16 @@ def main():
     host = None
     if world == 1 and not args.no_host_path:
         host = host_buffer_leg(runner, u, n_per_gpu, T, model)
+    # BASELINE configs 2, 4 and 5 next to the headline (config 3): one short steady-state measurement each, reported
+    # under config.other_workloads -- every BASELINE number in the driver's own record.  Never `value`.
+    others = None
+    if world == 1 and args.workload == "superover_grid" and not args.no_other_workloads:
+        others = []
+        for wl in ("diodeclipper_sweep", "superover_montecarlo", "birdie_grid"):
+            try:
+                others.append(other_workload_leg(wl, local_rank, dev))
+            except Exception as e:      # (the headline line must come out whatever happens here)
+                others.append({"workload": wl, "error": repr(e)})
     if rank == 0:
         units = world * n_per_gpu * T * args.steps
         value = units / elapsed
@@ -553,6 +624,8 @@ def main():
         iters_per_sample = iters_total / units
         abytes = algorithmic_bytes(model, n_per_gpu, T)
         achieved = abytes / (last_ms * 1e-3) / 1e9
+        prec = pmc_record(args.workload, n_per_gpu, T, model.solver, kernel_name(runner), last_ms)
+        fx = pmc_fp64_executed_flops(prec)
         out = {
             "metric": {"diodeclipper_sweep": "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)",
                        "birdie_grid": "circuit-instance*samples/sec (birdie, 176.4 kHz)"}.get(
@@ -589,6 +662,7 @@ def main():
                 "cold_first_step_ms": cold_ms,
                 "value_host_buffers": host["steady_value"] if host else None,
                 "host_buffers": host,
+                "other_workloads": others,
                 "timed_steps_note": "the timed steps continue the signal of the warm-up steps: warm solver state and "
                                     "solution caches (steady state); cold_first_step_ms is the first step of the fresh batch",
                 "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,
@@ -598,29 +672,38 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, n_per_gpu, T),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(prec),
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
                 "kernel": kernel_name(runner),
                 "kernel_ms": last_ms, "algorithmic_bytes_per_launch": abytes,
-                "note": "path is bound by per-wave instruction issue/fetch, not by HBM (DESIGN.md 2); fp64 figure below",
-                "fp64_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
+                "note": "path is bound by per-wave instruction issue/fetch, not by HBM (DESIGN.md 2).  Two fp64 figures: "
+                        "fp64_executed_* = the fp64 instructions the kernel executed (PMC SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 "
+                        "lanes, FMA = 2 flop; masked lanes included) -- the pipe's utilisation; fp64_reference_equivalent_* = the "
+                        "flop model of SURVEY 8(d) at the measured Newton iterations per sample -- the work the REFERENCE's "
+                        "algorithm does for the same samples: it counts a dense 13 x 13 LU and 29-row q products per iteration, "
+                        "which the condensed kernel does not perform (7-step elimination on the reduced system), so it is a "
+                        "work-equivalent rate, not utilisation",
+                "fp64_executed_tflops": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12) if fx else None,
+                "fp64_executed_frac": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if fx else None,
+                "fp64_reference_equivalent_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
                 / (last_ms * 1e-3) / 1e12 if model.subs else None,
                 "fp64_peak_tflops": FP64_PEAK_TFLOPS,
-                "lds_bank_conflict_frac": pmc_lds_bank_conflict_frac(args.workload, n_per_gpu, T),
-                "valu_issue_frac": pmc_valu_issue_frac(args.workload, n_per_gpu, T),
-                "valu_issue_profiled_kernel_ms": (pmc_record(args.workload, n_per_gpu, T) or {}).get("kernel_avg_ms_profiled"),
+                "lds_bank_conflict_frac": pmc_lds_bank_conflict_frac(prec),
+                "valu_issue_frac": pmc_valu_issue_frac(prec),
+                "valu_issue_profiled_kernel_ms": (prec or {}).get("kernel_avg_ms_profiled"),
                 "valu_issue_note": "VALU wave-instructions issued / (1024 SIMDs x cycles / 4) and LDS bank-conflict cycles / "
-                                   "LDS-active cycles, from the committed rocprofv3 PMC passes of this workload "
-                                   "(profiles/pmc_traffic.json, tools/profile_gpu.sh: means over the dispatches of the TIMED "
-                                   "steps only, whose mean duration is valu_issue_profiled_kernel_ms); null if none",
+                                   "LDS-active cycles, from the committed rocprofv3 PMC passes of this workload, solver stack and "
+                                   "kernel variant (profiles/pmc_traffic.json, tools/profile_gpu.sh: means over the dispatches of the "
+                                   "TIMED steps only, whose mean duration is valu_issue_profiled_kernel_ms and must lie within 3 % of "
+                                   "this run's kernel_ms); null if no such record is on file",
             },
         }
         if use_dist and not rehearsal:
             assert out["config"]["rccl_ranks"] == args.gpus == dist.get_world_size(), (world, args.gpus)
             assert dist.get_backend() == "nccl"
             assert len(set(checksums)) == world, f"ranks computed identical shards: {checksums}"
-        if out["roofline"]["fp64_tflops"] is not None:
-            out["roofline"]["fp64_frac"] = out["roofline"]["fp64_tflops"] / FP64_PEAK_TFLOPS
+        if out["roofline"]["fp64_reference_equivalent_tflops"] is not None:
+            out["roofline"]["fp64_reference_equivalent_frac"] = out["roofline"]["fp64_reference_equivalent_tflops"] / FP64_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             T_cpu = args.cpu_samples or min(T, FS)
             out["cpu_baseline"] = cpu_baseline(fixture, model, pots, amp, T_cpu, fs=fs)

@@ -122,8 +122,10 @@ void acme_model_destroy(acme_model *m);
 /* dims = {nn, nq, np, nx, nu, ny} of the instantiated kernel shape the model runs in */
 int acme_model_kernel_shape(const acme_model *m, int dims[6]);
 /* which kernel variant the model runs in: *condensed_rows = number of residual rows eliminated ahead of
- * the Newton iteration (the potentiometer rows of DESIGN.md 2 "Round 4"; 0 = none), *generic = 1 when no
- * instantiated shape holds the model and the run-time-sized kernel takes it.  Either pointer may be null. */
+ * the Newton iteration (the potentiometer rows of DESIGN.md 2 "Round 4"; 0 = none), *generic = 0 for a tuned
+ * shape; 2 when no instantiated shape holds the model and the cooperative run-time-sized kernel takes it (one
+ * sub-problem of up to 64 unknowns, working arrays in LDS: csrc/acme_coop.h); 1 for the lane-per-instance kernel
+ * that takes everything else (csrc/acme_generic.h).  Either pointer may be null. */
 int acme_model_kernel_variant(const acme_model *m, int *condensed_rows, int *generic);
 
 /* ---- batch: N instances + their device-resident mutable state ----------------------- */

@@ -18,6 +18,7 @@
 #include "../../acme_jl_amd/csrc/acme_kernel.h"
 #include "../../acme_jl_amd/csrc/acme_lane_kernel.h"
 #include "../../acme_jl_amd/csrc/acme_pack.h"
+#include "../../acme_jl_amd/csrc/acme_coop.h"
 
 using namespace acme;
 
@@ -249,6 +250,25 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) {
 // the generic kernel has no cross-lane operation: its "lanes" run one after the other
 static inline int launch_generic(const GArgs &A, stream_t) {
     for (long long i = 0; i < A.n_inst; ++i) gen_main(A, i);
+    return 0;
+}
+// the mid-size kernel (acme_coop.h): an emulated block is four of its one-wave blocks
+struct CoopLaunch { const GArgs *A; double *lds; size_t per_wave; int bid; };
+static void coop_fiber_entry(void *p) {
+    CoopLaunch *c = (CoopLaunch *)p;
+    const int tid = wv::tid(), wave = tid >> 6;
+    if (c->A->coop_imgl != 0) coop_main<true>(*c->A, c->lds + (size_t)wave * c->per_wave, c->bid * WAVES_PER_BLOCK + wave, tid & 63);
+    else coop_main<false>(*c->A, c->lds + (size_t)wave * c->per_wave, c->bid * WAVES_PER_BLOCK + wave, tid & 63);
+}
+static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t) {
+    const size_t per_wave = lds_bytes / sizeof(double);
+    std::vector<double> lds(per_wave * WAVES_PER_BLOCK + 64);
+    const long long waves = (A.n_inst + A.coop_gpw - 1) / A.coop_gpw;
+    for (long long b = 0; b * WAVES_PER_BLOCK < waves; ++b) {
+        for (auto &v : lds) v = std::nan("");
+        CoopLaunch c{&A, lds.data(), per_wave, (int)b};
+        emu::run_block((int)b, &coop_fiber_entry, &c);
+    }
     return 0;
 }
 // placement of the waves by their measured cost (acme_balance.h): the two passes, one "thread" after the other

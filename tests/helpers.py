@@ -169,7 +169,8 @@ def moving_pot_inputs(N, T, seed=5):
 
 def beyond_the_tuned_shapes():
     """(name, model, u[N, nu, T]) for models no tuned kernel shape holds -- 20 unknowns in one sub-problem, six
-    nonlinear sub-problems, 40 states: the generic lane-per-instance kernel (acme_generic.h) takes them."""
+    nonlinear sub-problems, 40 states: the run-time-sized kernels take them (one sub-problem of up to 64 unknowns, or none:
+    the cooperative mid-size kernel acme_coop.h; anything else: the lane-per-instance kernel acme_generic.h)."""
     from fractions import Fraction
     import circuits
     from acme_jl_amd import examples
@@ -180,3 +181,16 @@ def beyond_the_tuned_shapes():
     return [("20 unknowns", DiscreteModel(circuits.clipper_chain(10), t, HS, decompose_nonlinearity=False), u),
             ("6 sub-problems", DiscreteModel(circuits.buffered_clipper_chain(6), t, HS), u),
             ("40-stage RC ladder", DiscreteModel(examples.rc_ladder(40), t, HS), u)]
+
+
+def mid_size_models():
+    """(name, model, u[N, nu, T]) in the cooperative mid-size kernel's range (csrc/acme_coop.h): ONE sub-problem of 24 / 32
+    unknowns -- two rows per lane, the second group of 16 rows full or half full."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import DiscreteModel
+    t = Fraction(1, FS)
+    amp = np.array([0.05, 0.4, 1.0, 2.5, 4.0])          # (5 instances: a wave of four and a wave of one)
+    u = amp[:, None, None] * sine(120)[None, None, :]
+    return [("24 unknowns", DiscreteModel(circuits.clipper_chain(12), t, HS, decompose_nonlinearity=False), u),
+            ("32 unknowns", DiscreteModel(circuits.clipper_chain(16), t, HS, decompose_nonlinearity=False), u)]

@@ -19,15 +19,36 @@ def test_superover_grid_layout():
 
 
 def test_traffic_lookup_and_byte_model():
-    assert bench.pmc_traffic("superover_grid", 8192, 44100) > 1.4e10     # committed PMC pass
-    assert bench.pmc_traffic("superover_grid", 8192, 123) is None
+    r = bench.pmc_record("superover_grid", 8192, 44100)          # committed PMC pass of the headline
+    assert r is not None and bench.pmc_traffic(r) > 1.4e10
+    assert bench.pmc_record("superover_grid", 8192, 123) is None and bench.pmc_traffic(None) is None
     # the steady-state counters the bench line's roofline object quotes (tools/profile_gpu.sh, tools/merge_pmc.py)
-    assert 0.0 < bench.pmc_lds_bank_conflict_frac("superover_grid", 8192, 44100) < 0.02
-    assert 0.6 < bench.pmc_valu_issue_frac("superover_grid", 8192, 44100) < 1.0
-    assert bench.pmc_lds_bank_conflict_frac("superover_grid", 8192, 123) is None
+    assert 0.0 < bench.pmc_lds_bank_conflict_frac(r) < 0.02
+    assert 0.6 < bench.pmc_valu_issue_frac(r) < 1.0
+    assert bench.pmc_lds_bank_conflict_frac(None) is None
     from helpers import load
     m = load("superover_var")
     assert bench.algorithmic_bytes(m, 8192, 44100) == 8192 * 44100 * 40 + 8192 * 2 * 8 * (11 + 11 + 13)
+
+
+def test_pmc_record_never_quotes_a_stale_or_foreign_pass():
+    """A bench line quotes PMC figures only from a pass of ITS configuration: same workload, size, solver stack and kernel
+    variant, profiled launches within 3 % of its own kernel time (the cache-less line quoted the caching
+    run's counters, the diode-clipper record was a round older than its kernel)."""
+    r = bench.pmc_record("superover_grid", 8192, 44100)
+    ms = r["kernel_avg_ms_profiled"]
+    assert bench.pmc_record("superover_grid", 8192, 44100, kernel_ms=ms * 1.02) is r or \
+        bench.pmc_record("superover_grid", 8192, 44100, kernel_ms=ms * 1.02) == r
+    assert bench.pmc_record("superover_grid", 8192, 44100, kernel_ms=ms * 1.05) is None
+    assert bench.pmc_record("superover_grid", 8192, 44100, kernel_ms=ms * 2.1) is None       # (the 624 ms cache-less run)
+    assert bench.pmc_record("superover_grid", 8192, 44100, solver="no such stack") is None
+    assert bench.pmc_record("superover_grid", 8192, 44100, kernel="acme_run_kernel<Shape<1,2,3,4,5,6>>") is None
+    if r.get("solver"):      # records written from round 5 on carry what they ran
+        assert bench.pmc_record("superover_grid", 8192, 44100, solver=r["solver"], kernel=r["kernel"], kernel_ms=ms) == r
+    # executed fp64 work: 64 lanes x (2 FMA + MUL + ADD + TRANS)
+    fake = dict(sq_insts_valu_fma_f64_per_launch=10.0, sq_insts_valu_mul_f64_per_launch=3.0, sq_insts_valu_add_f64_per_launch=2.0,
+                sq_insts_valu_trans_f64_per_launch=1.0)
+    assert bench.pmc_fp64_executed_flops(fake) == 64.0 * 26.0 and bench.pmc_fp64_executed_flops({}) is None
 
 
 def test_montecarlo_models_are_seeded_per_rank():

@@ -865,3 +865,33 @@ def test_emulated_mosfet_polynomial_cap_is_reported_by_the_abi(emu_lib):
                                      roff.ctypes.data_as(ip), par.ctypes.data_as(dp))
     assert rc < 0 and b"1 ... 4 coefficients" in L.acme_last_error()
     L.acme_model_destroy(mh)
+
+
+def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
+    """The cooperative mid-size kernel (csrc/acme_coop.h: one instance per 16 lanes, rows dealt out over the lanes, working
+    arrays in LDS) on one sub-problem of 20 / 24 / 32 unknowns: the oracle's outputs and iteration totals on both solver
+    stacks, across a launch boundary; the same from private model images (the image then stays in HBM); and the
+    lane-per-instance kernel (ACME_COOP=0) agrees -- the two restate the same arithmetic entry by entry."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
+    for name, m, u in mid_size_models() + beyond_the_tuned_shapes()[:1]:
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m.solver = solver
+            yref, its = oracle_run(m, u, cache_limit=lim)
+            outs = {}
+            for variant in ("coop", "coop, private images", "lane per instance"):
+                if variant == "lane per instance":
+                    monkeypatch.setenv("ACME_COOP", "0")
+                else:
+                    monkeypatch.delenv("ACME_COOP", raising=False)
+                models = [m] * u.shape[0] if "private" in variant else None
+                r = ModelRunner(m, u.shape[0], lib=emu_lib, models=models)
+                assert r.kernel_family() == ("generic" if variant == "lane per instance" else "coop"), (name, variant)
+                y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+                assert_close(y, yref, rtol=RTOL_SAME)
+                assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, variant)
+                outs[variant] = y
+            monkeypatch.delenv("ACME_COOP", raising=False)
+            assert np.array_equal(outs["coop"], outs["coop, private images"]), name
+            assert np.abs(outs["coop"] - outs["lane per instance"]).max() <= 1e-13 * max(1.0, np.abs(yref).max()), name

@@ -833,3 +833,31 @@ def test_host_arrays_may_be_freed_after_any_call(hip_lib):
     r3 = ModelRunner(m, N, lib=hip_lib)
     y3 = r3.run(u[:, :, :100])                  # a launch right behind the failed un-registration
     assert np.array_equal(np.transpose(y3, (0, 2, 1)), yd[:, :100, :])
+
+
+def test_mid_size_kernel(hip_lib, monkeypatch):
+    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 20 unknowns (what the reference's LU "for sizes up to about
+    60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full waves and a ragged
+    last one): the oracle's outputs (RTOL_SAME) and iteration totals, and the lane-per-instance kernel's."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
+    for name, m, u5 in mid_size_models() + beyond_the_tuned_shapes()[:1]:
+        N, T = 70, u5.shape[2]
+        u = np.logspace(-1.5, 0.6, N)[:, None, None] * u5[2:3] / np.abs(u5[2]).max()
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m.solver = solver
+            yref, its = oracle_run(m, u, cache_limit=lim)
+            r = ModelRunner(m, N, lib=hip_lib)
+            assert r.kernel_family() == "coop"
+            y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+            err = assert_close(y, yref, rtol=RTOL_SAME)
+            assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
+            monkeypatch.setenv("ACME_COOP", "0")
+            r0 = ModelRunner(m, N, lib=hip_lib)
+            assert r0.kernel_family() == "generic"
+            y0 = np.concatenate([r0.run(u[:, :, :50]), r0.run(u[:, :, 50:])], axis=2)
+            monkeypatch.delenv("ACME_COOP")
+            print(f"mid-size kernel, {name}, {solver}: rel err vs oracle {err:.2e}, vs the lane-per-instance kernel "
+                  f"{np.abs(y - y0).max():.2e}, iterations {int(its.sum())} = oracle's")
+            assert np.abs(y - y0).max() <= 1e-13 * max(1.0, np.abs(yref).max())

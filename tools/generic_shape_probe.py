@@ -29,6 +29,9 @@ cases = [
     # beyond the tuned shapes: the generic lane-per-instance kernel (acme_generic.h)
     ("clipper chain, 10 stages (nn 20) [generic]", DiscreteModel(circuits.clipper_chain(10), t, CachingHomotopySolver, decompose_nonlinearity=False)),
     ("buffered clipper chain, 6 stages (nsub 6) [generic]", DiscreteModel(circuits.buffered_clipper_chain(6), t, CachingHomotopySolver)),
+    # the cooperative mid-size kernel's range (acme_coop.h; ACME_COOP=0: the lane-per-instance kernel)
+    ("clipper chain, 12 stages (nn 24) [generic]", DiscreteModel(circuits.clipper_chain(12), t, CachingHomotopySolver, decompose_nonlinearity=False)),
+    ("clipper chain, 16 stages (nn 32) [generic]", DiscreteModel(circuits.clipper_chain(16), t, CachingHomotopySolver, decompose_nonlinearity=False)),
 ]
 if len(sys.argv) > 3:      # a subset by substring
     cases = [c for c in cases if sys.argv[3] in c[0]]
@@ -55,6 +58,6 @@ for name, m in cases:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ra = r.report_arrays()
-    print(f"{name:48s} shape {r.kernel_shape()} [{len(m.subs)} sub]: {N * T / dt:.3e} inst*samples/s, "
+    print(f"{name:48s} shape {r.kernel_shape()} {r.kernel_family()} [{len(m.subs)} sub]: {N * T / dt:.3e} inst*samples/s, "
           f"{ra['iters_total'].sum() / (N * T):.2f} its/sample, warnings {int(ra['n_warn'].sum())}, finite {bool(torch.isfinite(y).all())}",
           flush=True)

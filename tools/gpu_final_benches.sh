@@ -2,7 +2,7 @@
 # bench lines of every BASELINE configuration with the current library -> gpurun_out/<tag>/
 cd $GRAFT_REPO_ROOT
 tag=$1; mkdir -p gpurun_out/$tag
-run() { name=$1; shift; timeout 200 python bench.py --no-cpu-baseline "$@" > gpurun_out/$tag/bench_$name.json 2> gpurun_out/$tag/bench_$name.err; python - gpurun_out/$tag/bench_$name.json $name <<'PY'
+run() { name=$1; shift; timeout 200 python bench.py --no-cpu-baseline --no-other-workloads "$@" > gpurun_out/$tag/bench_$name.json 2> gpurun_out/$tag/bench_$name.err; python - gpurun_out/$tag/bench_$name.json $name <<'PY'
 import sys, json
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -13,20 +13,23 @@ mkdir -p "$OUT"
 export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp
 export WARM=${WARMUP:-3} NSTEPS=${STEPS:-3}
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps $NSTEPS --warmup $WARM $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-host-path --no-other-workloads --steps $NSTEPS --warmup $WARM $*"
 export BENCH_ARGS="$*"
 echo "== kernel trace + stats"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
 tail -1 "$OUT/trace.log" > "$OUT/bench_line.json"
 echo "== pmc: HBM read"
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 echo "== pmc: HBM write"
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write.log" 2>&1
 echo "== pmc: SQ (LDS conflicts, VALU, waits)"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_sq" -o bench -- $BENCH > "$OUT/pmc_sq.log" 2>&1
+echo "== pmc: executed fp64 arithmetic"
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
+    -d "$OUT/pmc_f64" -o bench -- $BENCH > "$OUT/pmc_f64.log" 2>&1
 echo "== pmc: SQ2 (waits, branches, fetch)"
-rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQ_WAVES \
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQ_WAVES \
     -d "$OUT/pmc_sq2" -o bench -- $BENCH > "$OUT/pmc_sq2.log" 2>&1
 python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import collections, glob, json, os, shlex, sqlite3, sys
@@ -39,9 +42,9 @@ kern = {}
 for f in sorted(glob.glob(out + "/trace/**/*.db", recursive=True)):
     con = sqlite3.connect(f)
     print("== rocprofv3 --kernel-trace --stats: top kernels (all dispatches)")
-    print("%-86s %6s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    print("%-86s %6s %14s %14s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for r in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 5"):
-        print("%-86s %6d %14.1f %14.1f %8.3f" % (r[0][:86], r[1], r[2] / 1e3, r[3] / 1e3, r[4]))
+        print("%-86s %6d %14.3f %14.3f %8.3f" % (r[0][:86], r[1], r[2] / 1e6, r[3] / 1e6, r[4]))      # (the table holds nanoseconds)
     rows = con.execute("select name, start, end, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x "
                        "from kernels where " + sel + " order by start").fetchall()
     steady = rows[warm:]
@@ -53,7 +56,7 @@ for f in sorted(glob.glob(out + "/trace/**/*.db", recursive=True)):
               % (len(d), kern["avg_us"], kern["min_us"], kern["max_us"], r[3], r[4], r[5], r[6], r[7], r[8], r[9]))
         print("   kernel: " + r[0])
 vals = {}
-for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64", "pmc_sq2"):
     for f in sorted(glob.glob(out + f"/{grp}/**/*.db", recursive=True)):
         con = sqlite3.connect(f)
         print("== counters", grp, "(per dispatch, timed steps only)")
@@ -72,7 +75,15 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     wl = opt("--workload", "superover_grid")
     n_def = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(wl, 8192)      # bench.py's defaults
     t_def = 176400 if wl == "birdie_grid" else 44100
+    try:        # what exactly ran: the traced run's own bench line (solver stack, kernel variant, its kernel_ms)
+        line = json.loads(open(out + "/bench_line.json").read().strip().splitlines()[-1])
+    except Exception:
+        line = {}
     rec = {"workload": wl, "instances": int(opt("--instances", n_def)), "samples": int(opt("--samples", t_def)),
+           "solver": line.get("config", {}).get("solver"), "kernel": line.get("roofline", {}).get("kernel"),
+           "bench_kernel_ms": line.get("roofline", {}).get("kernel_ms"),
+           "sq_insts_valu_fma_f64_per_launch": vals.get("SQ_INSTS_VALU_FMA_F64"), "sq_insts_valu_mul_f64_per_launch": vals.get("SQ_INSTS_VALU_MUL_F64"),
+           "sq_insts_valu_add_f64_per_launch": vals.get("SQ_INSTS_VALU_ADD_F64"), "sq_insts_valu_trans_f64_per_launch": vals.get("SQ_INSTS_VALU_TRANS_F64"),
            "fetch_size_kb_per_launch": vals["FETCH_SIZE"], "write_size_kb_per_launch": vals["WRITE_SIZE"],
            "sq_insts_valu_per_launch": vals.get("SQ_INSTS_VALU"), "sq_insts_salu_per_launch": vals.get("SQ_INSTS_SALU"),
            "sq_insts_lds_per_launch": vals.get("SQ_INSTS_LDS"), "sq_insts_branch_per_launch": vals.get("SQ_INSTS_BRANCH"),
@@ -88,6 +99,10 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         print("lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.4f" % (vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]))
     if vals.get("GRBM_GUI_ACTIVE") and vals.get("SQ_INSTS_VALU"):
         print("valu_issue_frac = SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs / 4) = %.4f" % (vals["SQ_INSTS_VALU"] / (1024 * vals["GRBM_GUI_ACTIVE"] / 8 / 4)))
+    if vals.get("SQ_INSTS_VALU_FMA_F64") is not None and kern:
+        fl = 64.0 * (2 * vals["SQ_INSTS_VALU_FMA_F64"] + vals.get("SQ_INSTS_VALU_MUL_F64", 0) + vals.get("SQ_INSTS_VALU_ADD_F64", 0) + vals.get("SQ_INSTS_VALU_TRANS_F64", 0))
+        print("executed fp64: 64 lanes x (2 FMA + MUL + ADD + TRANS) = %.4g flop per launch = %.2f TFLOP/s over %.1f ms (masked lanes counted: an upper bound of useful work)"
+              % (fl, fl / (kern["avg_us"] * 1e-6) / 1e12, kern["avg_us"] / 1e3))
 PY
 # the rocpd databases (tens of MB per pass) have served their purpose: gpurun merges at most 64 MiB back
 find "$OUT" -name "*.db" -delete

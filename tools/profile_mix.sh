@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/mix_$TAG
 mkdir -p "$OUT"
 export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline $*"
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT \
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-host-path --no-other-workloads $*"
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT \
     -d "$OUT/p1" -o bench -- $BENCH > "$OUT/p1.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_EXP_GDS SQ_INSTS_FLAT SQ_INSTS_VSKIPPED \
+timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_EXP_GDS SQ_INSTS_FLAT SQ_INSTS_VSKIPPED \
     -d "$OUT/p2" -o bench -- $BENCH > "$OUT/p2.log" 2>&1
 python - "$OUT" "$TAG" <<'PY' | tee "$OUT/summary.txt"
 import glob, sys, sqlite3
