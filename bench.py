@@ -119,12 +119,16 @@ def pmc_record(workload, n, T, solver=None, kernel=None, kernel_ms=None):
     return None
 
 
-def kernel_name(runner):
+def kernel_name(runner, per_instance=False):
     """the dominant kernel as the rocprofv3 summaries name it (shape dimensions; condensed rows if any)"""
     nl, generic = runner.kernel_variant()
     if generic:
         return "acme_generic_kernel (run-time dimensions %d,%d,%d,%d,%d,%d)" % runner.kernel_shape()
-    name = "acme_run_kernel<Shape<%d,%d,%d,%d,%d,%d" % runner.kernel_shape()
+    shape = runner.kernel_shape()
+    # (the two smallest shapes run one LANE per instance unless ACME_LANE_KERNEL=0 or the batch has private images:
+    # csrc/acme_api.inc use_lane_kernel)
+    lane = shape in ((2, 4, 1, 1, 1, 1), (2, 4, 2, 3, 1, 1)) and os.environ.get("ACME_LANE_KERNEL") != "0" and not per_instance
+    name = ("acme_lane_kernel" if lane else "acme_run_kernel") + "<Shape<%d,%d,%d,%d,%d,%d" % shape
     return name + (", condensed rows %d>>" % nl if nl else ">>")
 
 
@@ -329,7 +333,7 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     return out
 
 
-def other_workload_leg(workload, local_rank, dev, steps=2, warmup=2):
+def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3):
     """One short steady-state measurement of another BASELINE configuration (config.other_workloads; never `value`):
     the same procedure as the headline's timed steps -- fresh batch, `warmup` launches continuing into `steps` timed
     ones -- at the configuration's own size and solver stack."""
@@ -363,11 +367,19 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=2):
     elapsed = time.perf_counter() - t0
     ms_total, launches = runner.kernel_time()
     ra = runner.report_arrays()
-    return {"workload": workload, "config": {"diodeclipper_sweep": 2, "superover_montecarlo": 4, "birdie_grid": 5}[workload],
+    kname, kms = kernel_name(runner, workload == "superover_montecarlo"), ms_total / max(launches, 1)
+    prec = pmc_record(workload, n, T, model.solver, kname, kms)       # (this configuration's own PMC pass, or nothing)
+    fx = pmc_fp64_executed_flops(prec)
+    abytes = algorithmic_bytes(model, n, T)
+    roof = {"achieved": abytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": abytes, "traffic": pmc_traffic(prec), "valu_issue_frac": pmc_valu_issue_frac(prec),
+            "lds_bank_conflict_frac": pmc_lds_bank_conflict_frac(prec),
+            "fp64_executed_tflops": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12) if fx else None,
+            "profiled_kernel_ms": (prec or {}).get("kernel_avg_ms_profiled")}
+    return {"workload": workload, "roofline": roof, "config": {"diodeclipper_sweep": 2, "superover_montecarlo": 4, "birdie_grid": 5}[workload],
             "instances": n, "samples_per_step": T, "fs": fs, "solver": model.solver, "steps": steps, "warmup": warmup,
-            "value": n * T * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": ms_total / max(launches, 1),
-            "kernel": ("acme_lane_kernel<Shape<%d,%d,%d,%d,%d,%d>>" % runner.kernel_shape()) if workload == "diodeclipper_sweep"
-            and os.environ.get("ACME_LANE_KERNEL") != "0" else kernel_name(runner),
+            "value": n * T * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": kms,
+            "kernel": kname,
             "newton_iters_per_sample": float(ra["iters_total"].sum()) / (n * T * steps), "n_warn": float(ra["n_warn"].sum()),
             "y_abs_sum": float(torch.nan_to_num(y).abs().sum())}
 
@@ -624,7 +636,8 @@ def main():
         iters_per_sample = iters_total / units
         abytes = algorithmic_bytes(model, n_per_gpu, T)
         achieved = abytes / (last_ms * 1e-3) / 1e9
-        prec = pmc_record(args.workload, n_per_gpu, T, model.solver, kernel_name(runner), last_ms)
+        kname = kernel_name(runner, args.workload == "superover_montecarlo")
+        prec = pmc_record(args.workload, n_per_gpu, T, model.solver, kname, last_ms)
         fx = pmc_fp64_executed_flops(prec)
         out = {
             "metric": {"diodeclipper_sweep": "circuit-instance*samples/sec (diodeclipper, 44.1 kHz)",
@@ -674,7 +687,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(prec),
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
-                "kernel": kernel_name(runner),
+                "kernel": kname,
                 "kernel_ms": last_ms, "algorithmic_bytes_per_launch": abytes,
                 "note": "path is bound by per-wave instruction issue/fetch, not by HBM (DESIGN.md 2).  Two fp64 figures: "
                         "fp64_executed_* = the fp64 instructions the kernel executed (PMC SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 "

@@ -30,8 +30,8 @@ for step in "$@"; do
       timeout 600 python bench.py $a > $out/bench_$(echo "$a" | tr -c 'a-zA-Z0-9\n' '_').json 2> $out/bench.err
       tail -1 $out/bench_$(echo "$a" | tr -c 'a-zA-Z0-9\n' '_').json | cut -c1-600 ;;
     others) bash tools/gpu_final_benches.sh $tag ;;
-    profile) bash tools/profile_gpu.sh ${tag}_${arg:-superover_grid} ${arg:+--workload $arg} --steps 3 --warmup 2 2>&1 | tail -25 ;;
-    mix) bash tools/profile_mix.sh ${tag}_${arg:-superover_grid} ${arg:+--workload $arg} --steps 2 --warmup 1 2>&1 | tail -15 ;;
+    profile) bash tools/profile_gpu.sh ${tag}_${arg:-superover_grid} ${arg:+--workload $arg} 2>&1 | tail -30 ;;      # (STEPS / WARMUP from the environment: 3 / 3)
+    mix) bash tools/profile_mix.sh ${tag}_${arg:-superover_grid} ${arg:+--workload $arg} --steps 2 --warmup 1 2>&1 | tail -20 ;;
     hostreg) timeout 300 tools/ubench/hostreg 2>&1 | tee $out/hostreg.txt ;;
     probe) IFS=: read f a <<< "$arg"; timeout 900 python tools/$f ${a//,/ } 2>&1 | tee $out/probe_${f%.py}.txt | tail -40 ;;
     *) echo "unknown step $step" ;;

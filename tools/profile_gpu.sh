@@ -17,7 +17,7 @@ BENCH="python $ROOT/bench.py --no-cpu-baseline --no-host-path --no-other-workloa
 export BENCH_ARGS="$*"
 echo "== kernel trace + stats"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
-tail -1 "$OUT/trace.log" > "$OUT/bench_line.json"
+grep "^{\"metric\"" "$OUT/trace.log" | tail -1 > "$OUT/bench_line.json"      # (the log ends with the profiler's own lines)
 echo "== pmc: HBM read"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 echo "== pmc: HBM write"
