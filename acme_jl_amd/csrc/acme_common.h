@@ -187,6 +187,11 @@ struct KArgs {
     long long image_stride;  // 0: one shared image; else doubles between per-instance images
     const double *rowc;      // ROWC x 16 row constants (const index major)
     const int *rowi;         // ROWI x 16 row ints
+    // Per-instance ELEMENT TABLES (every model of the reference carries its own element closures, src/elements.jl:236-245,
+    // 309-406: a sweep over a diode's is or a transistor's beta): doubles / ints between the tables of consecutive
+    // instances in rowc / rowi; 0: one shared table.  A block then stages its 16 instances' tables in LDS, as it does
+    // their images.
+    long long table_stride, tablei_stride;
     const double *lanec;     // constant block of the lane-per-instance kernel (LaneLayout), or nullptr
     const double *u;         // [n_inst][T][nu_io]
     double *y;               // [n_inst][T][ny_io]

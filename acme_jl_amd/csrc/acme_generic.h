@@ -55,6 +55,7 @@ struct GArgs {
     long long image_stride;  // 0: shared; else doubles between per-instance images
     const double *rowc;      // row constants, blocks of 16 rows: [(R / 16) * ROWC + c] * 16 + R % 16
     const int *rowi;         // row ints, likewise with ROWI
+    long long table_stride, tablei_stride;      // per-instance element tables: doubles / ints between them (0: shared)
     const double *u;         // [n_inst][T][nu]
     double *y;               // [n_inst][T][ny]
     double *state;           // [n_inst][state_total]
@@ -86,14 +87,14 @@ struct GenCtx {
 };
 
 // rows' descriptors out of the row tables
-ACME_DEV void gen_rowdesc(const GArgs &A, int R, RowDesc &rd, int (&tc)[4]) {
+ACME_DEV void gen_rowdesc(const GArgs &A, int R, RowDesc &rd, int (&tc)[4], long long inst = 0) {
     const int blk = R / GROUP, ln = R % GROUP;
-    const int *ri = A.rowi + (long long)blk * ROWI * GROUP + ln;
+    const int *ri = A.rowi + inst * A.tablei_stride + (long long)blk * ROWI * GROUP + ln;
     rd.kind = ri[0 * GROUP];
     rd.erow = ri[1 * GROUP];
     rd.flags = ri[2 * GROUP];
     for (int t = 0; t < 4; ++t) tc[t] = ri[(3 + t) * GROUP];
-    rd.rc = A.rowc + (long long)blk * ROWC * GROUP + ln;
+    rd.rc = A.rowc + inst * A.table_stride + (long long)blk * ROWC * GROUP + ln;
     for (int c = 0; c < 8; ++c) rd.k[c] = rd.rc[c * GROUP];
 }
 
@@ -118,7 +119,7 @@ ACME_DEV void gen_evaluate(const GenCtx &c, const GenSub &s, int w_z) {
     for (int r = 0; r < s.nn; ++r) {
         RowDesc rd;
         int tc[4];
-        gen_rowdesc(c.A, s.row0 + r, rd, tc);
+        gen_rowdesc(c.A, s.row0 + r, rd, tc, c.i);
         double e[4], tv[4], res;
         for (int t = 0; t < 4; ++t) e[t] = c.W(H.w_q + tc[t]);
         const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
@@ -142,7 +143,7 @@ ACME_DEV void gen_calc_jp(const GenCtx &c, const GenSub &s) {
     for (int r = 0; r < s.nn; ++r) {
         RowDesc rd;
         int tc[4];
-        gen_rowdesc(c.A, s.row0 + r, rd, tc);
+        gen_rowdesc(c.A, s.row0 + r, rd, tc, c.i);
         for (int j = 0; j < s.np; ++j) {
             double acc = 0.0;
             for (int t = 0; t < 4; ++t) acc = fma(c.W(H.w_tv + 4 * r + t), c.M[s.o_pexp + j * s.nq + tc[t]], acc);

@@ -40,6 +40,7 @@ struct KernelEntry {
     int lds_shared, lds_per_inst, lds_low;  // doubles
     int state;                     // doubles of state per instance
     int cache_lds;                 // LDS doubles per instance of the solution caches (Shape::CACHEI)
+    int lds_tab, lds_tab_low;      // doubles more per block when the element tables are per instance (KArgs::table_stride)
     int lds_lane_plain, lds_lane_caching;   // doubles, lane kernel (0: shape not supported by it)
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, hipStream_t);
 };
@@ -56,6 +57,7 @@ template <class S> static KernelEntry make_entry(int index) {
         abort();
     return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB, S::NL}, f.lds, f.low, f.fn_lane,
                        S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
+                       S::lds_doubles(true, true) - S::lds_doubles(true, false), S::lds_doubles_low(true) - S::lds_doubles_low(false),
                        lane_lds<S>(false), lane_lds<S>(true), f.launch_lane};
 }
 

@@ -123,6 +123,8 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // pointers and branches out of the run kernel: small shapes +1 .. +4 %; the big one lost 1.5 % in round 2
     // and gains 1.6 % now that the run kernel's rare paths are laid out of line (round 3)
     static constexpr bool SOLVE_SPLIT = true;
+    // per-instance element tables (KArgs::table_stride) are compiled in
+    static constexpr bool TABLES = NL_ == 0;
     // The homotopy solver's direct attempt as the FIRST PASS of its bisection loop -- one inlined copy of the whole solver
     // stack in the kernel instead of two (round 3 peeled the direct attempt out of the loop: +1.2 ... +12.6 % on kernels
     // with registers to spare).  The condensed kernel has none: with the second copy its run kernel spilled 414 vector
@@ -183,8 +185,9 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     static constexpr int CACHEIH = NSUBr * CACHE1H;           // HBM doubles per instance
     // the solution caches sit at the end of the block's LDS and are only allocated (and touched) when
     // the batch runs the caching solver
-    ACME_HD static constexpr int lds_doubles(bool per_instance) {
-        return (per_instance ? INST_PER_BLOCK * IMGN : L.total) + NSUBr * (ROWC_L * GROUP + ROWI_L * GROUP) +
+    // (per_tables: per-instance element tables, KArgs::table_stride -- 16 of them per block instead of one)
+    ACME_HD static constexpr int lds_doubles(bool per_instance, bool per_tables = false) {
+        return (per_instance ? INST_PER_BLOCK * IMGN : L.total) + (per_tables ? INST_PER_BLOCK : 1) * NSUBr * (ROWC_L * GROUP + ROWI_L * GROUP) +
                INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
     }
     // The LOW-LDS kernel variant (wave_main<S, MODE, true>): for batches whose model images -- 16 private
@@ -194,18 +197,19 @@ template <int NN_, int NQ_, int NP_, int NX_, int NU_, int NY_, int RARE_ = 0, i
     // (every evaluate! waits for global loads), but no model the shape can hold is refused: the
     // reference derives and runs any model, one by one (src/ACME.jl:150, :650-664).
     static constexpr bool ROWC_G = RARE;      // LOW: row constants from HBM (same layout there as in LDS)
-    ACME_HD static constexpr int lds_doubles_low() {
-        return NSUBr * ((ROWC_G ? 0 : ROWC_L * GROUP) + ROWI_L * GROUP) + INST_PER_BLOCK * SCRATCH + WAVES_PER_BLOCK * ORIGIN;
+    ACME_HD static constexpr int lds_doubles_low(bool per_tables = false) {
+        return (per_tables ? INST_PER_BLOCK : 1) * NSUBr * ((ROWC_G ? 0 : ROWC_L * GROUP) + ROWI_L * GROUP) + INST_PER_BLOCK * SCRATCH +
+               WAVES_PER_BLOCK * ORIGIN;
     }
     // Blocks per CU the register budget is cut for (__launch_bounds__): two -- 256 VGPRs per lane -- unless
     // the shape's LDS footprint lets only ONE block (one wave per SIMD) live on a CU anyway: then the whole
     // 512-register file is the wave's (the generic 16-unknown shape spilled 435 registers to scratch under
     // the 256 limit)
-    static constexpr int OCC = sizeof(double) * lds_doubles(false) > 80 * 1024 ? 1 : 2;
+    static constexpr int OCC = sizeof(double) * lds_doubles(false, false) > 80 * 1024 ? 1 : 2;
     // shapes that can need it: anything that does not fit with private images and caches
-    static constexpr bool HAS_LOW = sizeof(double) * (lds_doubles(true) + INST_PER_BLOCK * CACHEI) > 160 * 1024 ||
-                                    sizeof(double) * (lds_doubles(false) + INST_PER_BLOCK * CACHEI) > 160 * 1024;
-    static_assert(sizeof(double) * (lds_doubles_low() + INST_PER_BLOCK * CACHEI) <= 160 * 1024, "the LOW-LDS variant must always fit");
+    static constexpr bool HAS_LOW = sizeof(double) * (lds_doubles(true, false) + INST_PER_BLOCK * CACHEI) > 160 * 1024 ||
+                                    sizeof(double) * (lds_doubles(false, false) + INST_PER_BLOCK * CACHEI) > 160 * 1024;
+    static_assert(sizeof(double) * (lds_doubles_low(false) + INST_PER_BLOCK * CACHEI) <= 160 * 1024, "the LOW-LDS variant must always fit");
 };
 
 // compile-time counted loops (indices are template constants: DPP lane selects and
@@ -782,6 +786,14 @@ ACME_DEV void eval_row(const RowDesc &rd, const double (&e)[NT], double exA, dou
 // MODE_RUN_STREAM: run! whose u is still being copied into HBM while the kernel runs (KArgs::u_ready; streamed
 // host-buffer runs) -- a variant of its own: the check in the tile fetch cost the lone waves of BASELINE config 5 3.9 %.
 enum { MODE_RUN = 0, MODE_JAC = 1, MODE_SOLVE = 2, MODE_RUN_STREAM = 3 };
+// the batch instance slot `slot` of a launch works on (KArgs::inst_map), clamped into the batch for the empty slots of an
+// incomplete last block: what a block stages for them does not matter, but it must be readable
+ACME_DEV long long slot_instance(const KArgs &A, long long slot) {
+    long long ii = slot < A.n_inst ? slot : A.n_inst - 1;
+    if (A.inst_map) ii = A.inst_map[ii];
+    return ii < 0 ? 0 : ii;
+}
+ACME_DEV long long block_instance(const KArgs &A, int g) { return slot_instance(A, (long long)wv::bid() * INST_PER_BLOCK + g); }
 template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_main(const KArgs &A, double *lds) {
     constexpr int NN = S::NN, NQ = S::NQ, NP = S::NP, NX = S::NX, NU = S::NU, NY = S::NY;
     constexpr int NQS = S::NQS, NXS = S::NXS, NT = S::NT, NSUB = S::NSUBr;
@@ -810,9 +822,18 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));   // the block's dynamic LDS starts at 0
     double *lds_img = lds;
     constexpr bool ROWC_G = LOW && S::ROWC_G;        // LOW (Shape::lds_doubles_low): no image in LDS, ...
-    double *lds_rowc = lds_img + (LOW ? 0 : per_inst ? INST_PER_BLOCK * S::IMGN : L.total);   // [NSUB][ROWC_L*16]
-    int *lds_rowi = (int *)(lds_rowc + (ROWC_G ? 0 : NSUB * S::ROWC_L * GROUP));               // [NSUB][ROWI*16]
-    double *lds_scr = reinterpret_cast<double *>(lds_rowi) + NSUB * S::ROWI_L * GROUP;
+    // element tables: one for the block, or one per instance of the block (KArgs::table_stride)
+    // (not in the condensed shapes: the mere presence of the per-instance path cost the headline kernel 0.8 % -- 279.2
+    // against 276.9 ms, ten more spilled registers; acme_batch_set_matrices refuses such batches, Shape::TABLES)
+#ifdef ACME_EXP_NO_INSTANCE_TABLES      // (developer A/B: the kernel without per-instance element tables)
+    constexpr bool per_tab = false;
+#else
+    const bool per_tab = S::TABLES && A.table_stride != 0;
+#endif
+    const int tabs = per_tab ? INST_PER_BLOCK : 1;
+    double *lds_rowc = lds_img + (LOW ? 0 : per_inst ? INST_PER_BLOCK * S::IMGN : L.total);   // [tabs][NSUB][ROWC_L*16]
+    int *lds_rowi = (int *)(lds_rowc + (ROWC_G ? 0 : tabs * NSUB * S::ROWC_L * GROUP));        // [tabs][NSUB][ROWI*16]
+    double *lds_scr = reinterpret_cast<double *>(lds_rowi) + tabs * NSUB * S::ROWI_L * GROUP;
     constexpr int OS = S::OSTRIDE;  // slab stride; only lanes lig < NN may store
     // this lane's entry in the wave's origin slab: MULT shapes read / write it as 16-byte pairs, at positions
     // chosen so that neither the ds_read_b128 nor the ds_write_b128 lane groups collide (acme_slab_layout.h)
@@ -823,8 +844,12 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     double *ojp = ojp0;            // origin's J^-1 * Jp, row lig: [j * OS]
     double *cch = cache0;          // solution cache of the current sub-problem: stored p's (LDS)
     double *czg = A.cache + (valid ? inst : 0) * S::CACHEIH + S::CACHEPM;  // ... and stored z's (HBM)
-    const double *rowc_s = ROWC_G ? A.rowc : lds_rowc;
-    const int *rowi_s = lds_rowi;
+    // this instance's tables (its own, or the block's)
+    const double *const rowc_b = ROWC_G ? A.rowc + (per_tab && valid ? inst * A.table_stride : 0)
+                                        : lds_rowc + (per_tab ? gib : 0) * (NSUB * S::ROWC_L * GROUP);
+    const int *const rowi_b = lds_rowi + (per_tab ? gib : 0) * (NSUB * ROWI * GROUP);
+    const double *rowc_s = rowc_b;
+    const int *rowi_s = rowi_b;
     {   // cooperative load of the model image(s) and the row tables
         const int nthreads = WAVES_PER_BLOCK * 64;
         if constexpr (LOW) {
@@ -841,16 +866,23 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                 for (int i = tid; i < S::IMGN; i += nthreads) lds_img[g * S::IMGN + i] = src[S::IMG0 + i];
             }
         }
-        for (int s = 0; s < (ROWC_G ? 0 : NSUB); ++s)     // only the constants this shape's row evaluation reads
-            for (int i = tid; i < S::ROWC_L * GROUP; i += nthreads) {
-                if constexpr (S::RCPAIR) {      // i = ((pair * 16 + row) * 2 + half)
-                    const int c = (i / (2 * GROUP)) * 2 + (i & 1), row = (i >> 1) & (GROUP - 1);
-                    lds_rowc[s * S::ROWC_L * GROUP + i] = c < UR_W1 - UR_SA + 1 ? A.rowc[(s * ROWC + S::RC0 + c) * GROUP + row] : 0.0;
-                } else {
-                    lds_rowc[s * S::ROWC_L * GROUP + i] = A.rowc[(s * ROWC + S::RC0) * GROUP + i];
+        for (int g = 0; g < tabs; ++g) {
+            // (the tables of the block's g-th instance, or the shared ones)
+            const long long ii = per_tab ? block_instance(A, g) : 0;
+            const double *src = A.rowc + ii * A.table_stride;
+            const int *srci = A.rowi + ii * A.tablei_stride;
+            double *dst = lds_rowc + g * (NSUB * S::ROWC_L * GROUP);
+            for (int s = 0; s < (ROWC_G ? 0 : NSUB); ++s)     // only the constants this shape's row evaluation reads
+                for (int i = tid; i < S::ROWC_L * GROUP; i += nthreads) {
+                    if constexpr (S::RCPAIR) {      // i = ((pair * 16 + row) * 2 + half)
+                        const int c = (i / (2 * GROUP)) * 2 + (i & 1), row = (i >> 1) & (GROUP - 1);
+                        dst[s * S::ROWC_L * GROUP + i] = c < UR_W1 - UR_SA + 1 ? src[(s * ROWC + S::RC0 + c) * GROUP + row] : 0.0;
+                    } else {
+                        dst[s * S::ROWC_L * GROUP + i] = src[(s * ROWC + S::RC0) * GROUP + i];
+                    }
                 }
-            }
-        for (int i = tid; i < NSUB * ROWI * GROUP; i += nthreads) lds_rowi[i] = A.rowi[i];
+            for (int i = tid; i < NSUB * ROWI * GROUP; i += nthreads) lds_rowi[g * (NSUB * ROWI * GROUP) + i] = srci[i];
+        }
     }
     wv::block_sync();
 
@@ -1558,8 +1590,8 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
     auto enter_sub = [&](auto sc) ACME_LAMBDA {
         constexpr int s = decltype(sc)::value;
         Ms = M + L.sub0 + s * L.sub_stride;
-        rowc_s = ROWC_G ? A.rowc + s * ROWC * GROUP : lds_rowc + s * S::ROWC_L * GROUP;
-        rowi_s = lds_rowi + s * ROWI * GROUP;
+        rowc_s = rowc_b + s * (ROWC_G ? ROWC * GROUP : S::ROWC_L * GROUP);
+        rowi_s = rowi_b + s * ROWI * GROUP;
         ojp = ojp0 + s * S::ORIGIN1;
         cch = cache0 + s * S::CACHE1;
         czg = A.cache + (valid ? inst : 0) * S::CACHEIH + s * S::CACHE1H + S::CACHEPM;

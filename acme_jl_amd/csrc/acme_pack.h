@@ -9,6 +9,7 @@
 // the element functions (src/elements.jl) pre-evaluated in the same operation order.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <string>

@@ -27,13 +27,14 @@ def build(spec, circ=None):
     return circ
 
 
-def diodeclipper():
+def diodeclipper(is1=1e-15, is2=1.8e-15, eta1=1, eta2=1):
+    """examples/diodeclipper.jl:6-15; the diodes' parameters as arguments (sweeps over element parameters)"""
     return build([
         ("j_in", voltagesource(), {"-": "gnd"}),
         ("r1", resistor(1e3), {1: ("j_in", "+")}),
         ("c1", capacitor(47e-9), {1: ("r1", 2), 2: "gnd"}),
-        ("d1", diode(is_=1e-15), {"-": "gnd", "+": ("r1", 2)}),
-        ("d2", diode(is_=1.8e-15), {"-": ("r1", 2), "+": "gnd"}),
+        ("d1", diode(is_=is1, eta=eta1), {"-": "gnd", "+": ("r1", 2)}),
+        ("d2", diode(is_=is2, eta=eta2), {"-": ("r1", 2), "+": "gnd"}),
         ("j_out", voltageprobe(), {"-": "gnd", "+": ("r1", 2)}),
     ])
 

@@ -391,7 +391,9 @@ def host_buffer_leg(runner, u, N, T, model):
     from acme_jl_amd.runner import ACME_MEM_HOST
     dp = C.POINTER(C.c_double)
     uh = u.cpu().numpy()                       # [N][T][nu]: the ABI's (and Julia's nu x T x N) layout
-    yh = np.empty((N, T, model.ny))
+    yh = np.zeros((N, T, model.ny))
+    yh.fill(0.0)                               # (pages touched: the first call below is the library's cost, not the page faults
+                                               #  of a fresh 2.9 GB allocation, which any caller's first write pays)
 
     def call(ub, yb):
         t0 = time.perf_counter()

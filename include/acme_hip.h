@@ -134,9 +134,13 @@ int acme_batch_create(const acme_model *m, long long n_instances, const acme_opt
                       acme_batch **out);
 void acme_batch_destroy(acme_batch *b);
 
-/* per-instance matrices (Monte-Carlo component tolerances): instance i uses the matrices
- * of models[i]; all models must have the dimensions and element table of the batch's
- * model.  The instances take the freshly constructed state of their model (x = 0, each
+/* per-instance matrices (Monte-Carlo component tolerances, sweeps over element parameters): instance i uses the
+ * matrices AND the element closures' parameters of models[i] -- in the reference every model carries its own element
+ * closures (src/elements.jl:236-245, 309-406).  All models must have the batch model's dimensions and circuit
+ * STRUCTURE (the same element kinds in the same residual rows reading the same q entries); the element parameters
+ * -- a diode's is / eta, a transistor's betas, which Gummel-Poon refinements it has -- may differ: the batch then
+ * keeps one element table per instance (a block of the 16-lane kernels stages its 16 tables in LDS; if they do not
+ * fit a compute unit the call fails with ACME_ERR_UNSUPPORTED).  The instances take the freshly constructed state of their model (x = 0, each
  * solver's extrapolation origin at p = 0, z = the model's init_z; src/ACME.jl:145,253-259).
  * Only valid for batches created with per_instance_matrices = 1. */
 int acme_batch_set_matrices(acme_batch *b, long long first, long long count,

@@ -128,6 +128,7 @@ struct KernelEntry {
     KernelFns lds, low;
     const void *fn_lane;
     int lds_shared, lds_per_inst, lds_low, state, cache_lds;
+    int lds_tab, lds_tab_low;      // doubles more per block when the element tables are per instance (KArgs::table_stride)
     int lds_lane_plain, lds_lane_caching;
     int (*launch_lane)(const KArgs &, unsigned grid, size_t lds_bytes, void *);
 };
@@ -184,6 +185,7 @@ template <class S> static KernelEntry make_entry() {
     return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB, S::NL},
                        make_fns<S, false>(), make_fns<S, true>(), nullptr,
                        S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
+                       S::lds_doubles(true, true) - S::lds_doubles(true, false), S::lds_doubles_low(true) - S::lds_doubles_low(false),
                        lane_lds<S>(false), lane_lds<S>(true), &launch_any<S, 2>};
 }
 

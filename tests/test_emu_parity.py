@@ -895,3 +895,82 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
             monkeypatch.delenv("ACME_COOP", raising=False)
             assert np.array_equal(outs["coop"], outs["coop, private images"]), name
             assert np.abs(outs["coop"] - outs["lane per instance"]).max() <= 1e-13 * max(1.0, np.abs(yref).max()), name
+
+
+def element_parameter_sweeps():
+    """(name, models, u[N, nu, T]): batches whose instances differ in ELEMENT parameters -- every model of the reference
+    carries its own element closures (src/elements.jl:236-245, 309-406): a diode clipper swept over the diodes' saturation
+    currents and emission coefficients, and transistors with different Gummel-Poon refinements switched on (different
+    compile-time branches of the reference's closure, :331-396) in one batch."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import DiscreteModel
+    from helpers import HS, sine
+    t = Fraction(1, 44100)
+    n = 20
+    clip = [DiscreteModel(examples.diodeclipper(is1=1e-15 * 10 ** (3 * k / (n - 1)), is2=1.8e-15 * 10 ** (2 * (n - 1 - k) / (n - 1)),
+                                                eta1=1 + 0.05 * (k % 3), eta2=1 + 0.04 * (k % 4)), t, HS) for k in range(n)]
+    u_clip = np.linspace(0.2, 3.0, n)[:, None, None] * sine(150)[None, None, :]
+    isc, ise, etac, etae, bf, br = 1e-6, 2e-6, 1.1, 1.0, 100, 10
+    gp = []
+    for bits in (0, 1, 6, 17, 40, 64, 129, 200, 255):
+        kw = dict(ile=50e-9 if bits & 1 else 0, ilc=100e-9 if bits & 2 else 0, etacl=1.2 if bits & 4 else etac,
+                  etael=1.1 if bits & 8 else etae, vaf=10 if bits & 16 else np.inf, var=50 if bits & 32 else np.inf,
+                  ikf=50e-3 if bits & 64 else np.inf, ikr=500e-3 if bits & 128 else np.inf)
+        gp.append(DiscreteModel(circuits.bjt_test_circuit("npn", isc=isc * (1 + 0.1 * len(gp)), ise=ise, etac=etac, etae=etae, bf=bf + 10 * len(gp), br=br, **kw),
+                                Fraction(1), HS))
+    u_gp = np.tile(circuits.bjt_test_input("npn")[None], (len(gp), 1, 1))
+    return [("diode clipper, per-instance is / eta", clip, u_clip), ("BJT test circuit, per-instance Gummel-Poon branches", gp, u_gp)]
+
+
+def test_emulated_per_instance_element_parameters(emu_lib):
+    """acme_batch_set_matrices with models that differ in element PARAMETERS (same circuit structure): every instance
+    gets its own element table, a block stages its 16 tables in LDS -- against oracle runs of each instance's own model
+    (identical iteration totals); models of ANOTHER structure are refused."""
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import AcmeError, ModelRunner
+    from fractions import Fraction
+    from helpers import HS, RTOL_SAME
+    for name, models, u in element_parameter_sweeps():
+        r = ModelRunner(models[0], len(models), lib=emu_lib, models=models)
+        y = np.concatenate([r.run(u[:, :, :40]), r.run(u[:, :, 40:])], axis=2)
+        its = r.report_arrays()["iters_total"]
+        for k, m in enumerate(models):
+            yref, iref = oracle_run(m, u[k:k + 1])
+            assert_close(y[k:k + 1], yref, rtol=RTOL_SAME)
+            assert its[k] == iref[0], (name, k)
+        assert np.abs(y[0] - y[-1]).max() > 1e-6, name        # (the parameters matter)
+    with pytest.raises(AcmeError):
+        ModelRunner(models[0], 2, lib=emu_lib, models=[models[0], DiscreteModel(examples.diodeclipper(), Fraction(1, 44100), HS)])
+
+
+def test_emulated_per_instance_elements_and_condensed_shapes(emu_lib, monkeypatch):
+    """The condensed kernel shapes (potentiometers as inputs) do not carry the per-instance element path (it cost the
+    headline kernel 0.8 % by its mere presence): a batch of superover models with their own diode parameters is refused
+    there with a message naming the way out, and runs on the plain 13 x 13 shape (ACME_CONDENSE=0) against each model's
+    own oracle run."""
+    import copy
+    from acme_jl_amd.runner import AcmeError, ModelRunner
+    from helpers import HS, RTOL_SAME
+    base = load("superover_var", HS)
+    models = []
+    for k in range(3):
+        m = copy.deepcopy(base)
+        for e in m.subs[0].table:
+            if e["kind"] == 1:                     # the diodes: another saturation current per instance
+                e["par"] = [e["par"][0] * (1.0 + 0.5 * k), e["par"][1]]
+        models.append(m)
+    u = sweep_inputs("superover_var", 3, 60, seed=2)
+    with pytest.raises(AcmeError, match="ACME_CONDENSE=0"):
+        ModelRunner(models[0], 3, lib=emu_lib, models=models)
+    monkeypatch.setenv("ACME_CONDENSE", "0")
+    r = ModelRunner(models[0], 3, lib=emu_lib, models=models)
+    assert r.kernel_variant()[0] == 0
+    y = r.run(u)
+    for k, m in enumerate(models):
+        yref, its = oracle_run(m, u[k:k + 1])
+        assert_close(y[k:k + 1], yref, rtol=RTOL_SAME)
+        assert r.report_arrays()["iters_total"][k] == its[0]
+    assert np.abs(y[0] - y[2]).max() > 1e-9

@@ -118,30 +118,69 @@ def _gp_params(bits):
 
 def test_gummel_poon_full_grid(hip_lib):
     """test/runtests.jl:514-546 IN FULL on the HIP path: 2^8 parameter combinations x npn / pnp x 100 samples, the GPU's
-    (ve, vc, ie, ic) against the closed form at the reference's own atol = 1e-10."""
+    (ve, vc, ie, ic) against the closed form at the reference's own atol = 1e-10 -- as ONE batch of 512 instances with
+    per-instance model blocks AND per-instance element tables (every combination is another set of closure parameters and
+    another set of the closure's compile-time branches, src/elements.jl:331-396)."""
     import circuits
     from acme_jl_amd.model import DiscreteModel
     from acme_jl_amd.runner import ModelRunner
     isc, ise, etac, etae, bf, br = 1e-6, 2e-6, 1.1, 1.0, 100, 10
-    worst, shapes = 0.0, set()
+    models, us, meta = [], [], []
     for typ in ("npn", "pnp"):
-        u = circuits.bjt_test_input(typ)[None]
         for bits in range(256):
             p = _gp_params(bits)
-            m = DiscreteModel(circuits.bjt_test_circuit(typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br, **p), Fraction(1))
-            r = ModelRunner(m, 1, lib=hip_lib)
-            out = r.run(u)[0]
-            shapes.add(r.kernel_shape())
-            if typ == "pnp":
-                out = -out
-            ve, vc, ie, ic = out
-            i_f = bf / (1 + bf) * ise * (np.exp(ve / (etae * 25e-3)) - 1)
-            i_r = br / (1 + br) * isc * (np.exp(vc / (etac * 25e-3)) - 1)
-            icc = (2 * (1 - ve / p["var"] - vc / p["vaf"])) / (1 + np.sqrt(1 + 4 * (i_f / p["ikf"] + i_r / p["ikr"]))) * (i_f - i_r)
-            ibe = 1 / bf * i_f + p["ile"] * (np.exp(ve / (p["etael"] * 25e-3)) - 1)
-            ibc = 1 / br * i_r + p["ilc"] * (np.exp(vc / (p["etacl"] * 25e-3)) - 1)
-            e = max(float(np.abs(ie - (icc + ibe)).max()), float(np.abs(ic - (-icc + ibc)).max()))
-            worst = max(worst, e)
-            assert e <= 1e-10, (typ, bits, e)
-    print(f"Gummel-Poon grid: 512 models x 100 samples on the HIP path (kernel shapes {sorted(shapes)}), worst |error| vs the "
-          f"closed form {worst:.2e} A (reference atol 1e-10)")
+            models.append(DiscreteModel(circuits.bjt_test_circuit(typ, isc=isc, ise=ise, etac=etac, etae=etae, bf=bf, br=br, **p), Fraction(1)))
+            us.append(circuits.bjt_test_input(typ))
+            meta.append((typ, bits, p))
+    r = ModelRunner(models[-1], len(models), lib=hip_lib, models=models)
+    y = r.run(np.stack(us))
+    worst = 0.0
+    for (typ, bits, p), out in zip(meta, y):
+        if typ == "pnp":
+            out = -out
+        ve, vc, ie, ic = out
+        i_f = bf / (1 + bf) * ise * (np.exp(ve / (etae * 25e-3)) - 1)
+        i_r = br / (1 + br) * isc * (np.exp(vc / (etac * 25e-3)) - 1)
+        icc = (2 * (1 - ve / p["var"] - vc / p["vaf"])) / (1 + np.sqrt(1 + 4 * (i_f / p["ikf"] + i_r / p["ikr"]))) * (i_f - i_r)
+        ibe = 1 / bf * i_f + p["ile"] * (np.exp(ve / (p["etael"] * 25e-3)) - 1)
+        ibc = 1 / br * i_r + p["ilc"] * (np.exp(vc / (p["etacl"] * 25e-3)) - 1)
+        e = max(float(np.abs(ie - (icc + ibe)).max()), float(np.abs(ic - (-icc + ibc)).max()))
+        worst = max(worst, e)
+        assert e <= 1e-10, (typ, bits, e)
+    print(f"Gummel-Poon grid: 512 models x 100 samples as ONE batch on the HIP path (kernel shape {r.kernel_shape()}), worst |error| vs "
+          f"the closed form {worst:.2e} A (reference atol 1e-10)")
+
+
+def test_per_instance_element_parameters(hip_lib):
+    """A sweep over ELEMENT parameters as one batch: 64 diode clippers, every one with its own diode
+    saturation currents and emission coefficients, against oracle runs of the 64 exactly derived models (RTOL_SAME,
+    identical iteration totals); the emulator's mixed Gummel-Poon batch likewise."""
+    import sys
+    from helpers import RTOL_SAME, oracle_run, assert_close
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS
+    n, T = 64, 2000
+    t = Fraction(1, FS)
+    models = [DiscreteModel(examples.diodeclipper(is1=1e-15 * 10 ** (3 * k / (n - 1)), is2=1.8e-15 * 10 ** (2 * (n - 1 - k) / (n - 1)),
+                                                  eta1=1 + 0.05 * (k % 3), eta2=1 + 0.04 * (k % 4)), t, HS) for k in range(n)]
+    u = np.linspace(0.2, 3.0, n)[:, None, None] * sine(T)[None, None, :]
+    r = ModelRunner(models[0], n, lib=hip_lib, models=models)
+    y = np.concatenate([r.run(u[:, :, :700]), r.run(u[:, :, 700:])], axis=2)
+    its = r.report_arrays()["iters_total"]
+    worst = 0.0
+    for k, m in enumerate(models):
+        yref, iref = oracle_run(m, u[k:k + 1])
+        worst = max(worst, assert_close(y[k:k + 1], yref, rtol=RTOL_SAME))
+        assert its[k] == iref[0], k
+    print(f"64 diode clippers with their own is / eta in one batch ({r.kernel_shape()}): worst rel err vs the exact models' oracle {worst:.2e}, "
+          f"identical iteration totals")
+    from test_emu_parity import element_parameter_sweeps
+    name, gp, ugp = element_parameter_sweeps()[1]
+    rg = ModelRunner(gp[0], len(gp), lib=hip_lib, models=gp)
+    yg = rg.run(ugp)
+    for k, m in enumerate(gp):
+        yref, iref = oracle_run(m, ugp[k:k + 1])
+        assert_close(yg[k:k + 1], yref, rtol=RTOL_SAME)
+        assert rg.report_arrays()["iters_total"][k] == iref[0], k
