@@ -69,7 +69,11 @@ struct Packed {
 struct CondPlan {
     std::vector<int> lrows, lcols;      // residual rows / z columns, in pivot order
 };
-inline bool plan_condense(const HostSub &s, CondPlan &plan) {
+// forced: vet THIS model against a plan made for another (a batch's per-instance models take the batch model's plan, so
+// that they share its lane assignment): the same potentiometer rows must be linear here too (their `pos` driven by the
+// inputs alone) and A_LL with the plan's pivot columns well conditioned over the pots' travel for THIS model's
+// component values -- an instance with other resistor values is not vouched for by the batch model's check.
+inline bool plan_condense(const HostSub &s, CondPlan &plan, const CondPlan *forced = nullptr) {
     struct LinRow { int row, v, i; double r, w0, w1; int pot; };
     std::vector<LinRow> rows;
     int npots = 0;
@@ -108,7 +112,18 @@ inline bool plan_condense(const HostSub &s, CondPlan &plan) {
     for (int k = 0; k < nl; ++k) rleft[k] = k;
     for (int j = 0; j < nn; ++j) cleft[j] = j;
     std::vector<int> prow, pcol;
-    for (int step = 0; step < nl; ++step) {
+    if (forced) {
+        if ((int)forced->lrows.size() != nl || (int)forced->lcols.size() != nl) return false;
+        for (int k = 0; k < nl; ++k) {
+            int idx = -1;
+            for (int r = 0; r < nl; ++r)
+                if (rows[r].row == forced->lrows[k]) idx = r;
+            if (idx < 0 || forced->lcols[k] < 0 || forced->lcols[k] >= nn) return false;
+            prow.push_back(idx);
+            pcol.push_back(forced->lcols[k]);
+        }
+    }
+    for (int step = 0; step < (forced ? 0 : nl); ++step) {
         double best = 0.0;
         int br = -1, bc = -1;
         for (int r : rleft)
@@ -389,8 +404,12 @@ inline bool pack_model(const HostModel &m_in, Packed &P, std::string &err, const
         CondPlan plan;
         bool have = false;
         if (allowed && force_plan && !force_plan->lrows.empty()) {
-            plan.lrows = force_plan->lrows;
-            plan.lcols = force_plan->lcols;
+            const CondPlan fp{force_plan->lrows, force_plan->lcols};
+            if (!plan_condense(m_in.subs[0], plan, &fp)) {
+                err = "the batch model's condensation of the potentiometer rows does not hold for this instance's component values "
+                      "(a row is not linear here, or the linear block is ill conditioned): create the batch with ACME_CONDENSE=0";
+                return false;
+            }
             have = true;
         } else if (allowed && !force_plan) {
             have = plan_condense(m_in.subs[0], plan);

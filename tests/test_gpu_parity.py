@@ -861,3 +861,29 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             print(f"mid-size kernel, {name}, {solver}: rel err vs oracle {err:.2e}, vs the lane-per-instance kernel "
                   f"{np.abs(y - y0).max():.2e}, iterations {int(its.sum())} = oracle's")
             assert np.abs(y - y0).max() <= 1e-13 * max(1.0, np.abs(yref).max())
+
+
+def test_streamed_host_path_only_when_the_grid_is_resident(hip_lib):
+    """A streamed host-buffer run launches the kernel first and lets waves wait for their inputs to land (KArgs::u_ready);
+    that is only safe while every block of the grid is resident.  A retained-array run of 516 blocks on a chip
+    that holds 512 must take the sliced pipeline instead and give the device-resident run's bits; 512 blocks stream."""
+    import ctypes as C
+    import torch
+    from acme_jl_amd.runner import ACME_MEM_HOST, ModelRunner
+    m = load("superover_var")
+    T = 4501
+    dp = C.POINTER(C.c_double)
+    for N in (8192 + 64, 8192):
+        rng = np.random.default_rng(N)
+        ub = np.zeros((N, T, m.nu))
+        ub[:, :, 0] = rng.uniform(0.1, 1.0, N)[:, None] * sine(T)[None, :]
+        ub[:, :, 1:] = rng.uniform(0.05, 0.95, (N, 3))[:, None, :]
+        r = ModelRunner(m, N, lib=hip_lib)
+        r.set_host_retention(True)
+        yb = np.full((N, T, m.ny), np.nan)
+        r.lib.check(r.lib.L.acme_batch_run(r.h, ub.ctypes.data_as(dp), yb.ctypes.data_as(dp), T, ACME_MEM_HOST, None))
+        r.release_host_buffers()
+        ref = ModelRunner(m, N, lib=hip_lib)
+        yd = ref.run_torch(torch.from_numpy(ub).cuda()).cpu().numpy()
+        assert np.array_equal(yb, yd), N
+        assert np.array_equal(r.report_arrays()["iters_total"], ref.report_arrays()["iters_total"])
