@@ -1797,10 +1797,10 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             }
             d = (lig < count) ? d : (double)INFINITY;
             const double m = wv::allmin16(d);
-            const unsigned long long bal = wv::ballot(d == m);
-            const int idx = wv::ffs32((int)((bal >> (grp * GROUP)) & 0xFFFFull)) - 1;   // first nearest entry
             const bool hit = need && count > 0 && m < best;
             if (ACME_RARE(wv::ballot(hit))) {
+                const unsigned long long bal = wv::ballot(d == m);
+                const int idx = wv::ffs32((int)((bal >> (grp * GROUP)) & 0xFFFFull)) - 1;   // first nearest entry
                 const int e = hit ? idx : 0;
                 const double cpl = cp[(lig < NP ? lig : 0) * CACHE + e];
                 const double czl = (valid && caching) ? cz[e * NN + (lig < NN ? lig : 0)] : 0.0;   // HBM, one line
@@ -1881,8 +1881,19 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                     z0m = lz - tt;
                 }
             };
+            // an origin to (re-)linearise is known before the loop (a stale slab, a solution-cache hit: 13 ... 17 % of an
+            // instance's samples on the headline grid): straight into phase 0 -- the target's pfull is formed there anyway;
+            // every instance then takes part in the origin's condensation check (theirs is up to date).  One set_p less on
+            // those samples: 274.6 -> 272.2 ms on the headline (round 5)
+            const bool direct0 = wv::ballot(reorig) != 0ull;
             int ph = wv::opaque(1);
+            if (direct0) {
+                ph = wv::opaque(0);
+                back = true;
+            }
             for (;;) {
+                // (the target's pfull is formed a second time after phase 0; handing phase 0's copy over instead was measured:
+                // six more registers live across the phase -- 283.4 against 272.1 ms)
                 set_p(wv::settle(ph != 0 ? target : lp));
                 if (ph != 0 && !back) {
                     // an origin to (re-)linearise, or potentiometers that moved since the origin was taken (opos is not
@@ -1894,7 +1905,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
                         continue;
                     }
                 }
-                const bool part = ph != 0 ? need : (reorig || mvpre);
+                const bool part = ph != 0 ? need : (reorig || mvpre || direct0);
                 const bool chg = inst_any(part && islin && !(pf[2] == cpos));
                 if (ACME_RARE(wv::ballot(chg) != 0ull)) condense(chg);
                 prep_reduced();
