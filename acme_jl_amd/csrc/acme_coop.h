@@ -317,6 +317,182 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
     wv::wave_fence();
 }
 
+// ---- the factor matrix in REGISTERS (17 ... 32 unknowns: kernels instantiated per NC = the unknowns rounded up to 4) ----
+// The LDS version above walks the elimination through LDS: per step a pivot search, an interchange and an update, each a
+// round trip of LDS latency that a lone wave has nothing to hide behind (96 000 of 187 000 cycles per sample at 20 unknowns).
+// Here a lane reads its (up to two) rows ONCE (ds_read_b128), keeps them in registers through all n steps -- column indices
+// are compile-time constants, the step loop is written out -- and writes the factors once.  A row never moves: the
+// reference's full-row interchange becomes the row's POSITION label (pos: where the row would sit after the interchanges so
+// far), which is what decides a tie in the pivot search (first strict maximum = the smallest position) and where the row is
+// written at the end; the step's pivot row travels through LDS row k of the result (its final place), one write by its
+// holder and one broadcast read by everyone.  Arithmetic per entry: unchanged (l = a_ik * (1 / a_kk), a_ij -= l a_kj in
+// the order k = 0, 1, ...), so the factors, the gather and the zero-pivot verdict are coop_lu's bit for bit.
+constexpr int COOP_REG_SLOTS = 2;
+template <int NC> ACME_DEV bool coop_lu_reg(const CoopCtx &c, int n, int o_f, int o_src) {
+    static_assert(NC % 4 == 0 && NC <= GROUP * COOP_REG_SLOTS, "columns in pairs, two rows per lane");
+    constexpr int NS = COOP_REG_SLOTS;
+    double *W = c.W;
+    const int ld = c.H.ldf;
+    double *F = W + o_f;                      // 16-byte aligned rows (even offset, even pitch: acme_pack.h)
+    double a[NS][NC];
+    int pos[NS];
+    bool real[NS];
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int i = c.lig + GROUP * sl;
+        real[sl] = i < n;
+        pos[sl] = i;
+        sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            wv::pair_t v{0.0, 0.0};
+            if (real[sl]) v = wv::ld2(F + i * ld + 2 * g);
+            a[sl][2 * g] = v.lo;
+            a[sl][2 * g + 1] = v.hi;
+        });
+    });
+    wv::wave_fence();
+    bool ok = true;
+    sfor<0, NC>([&](auto kc) ACME_LAMBDA {
+        constexpr int k = decltype(kc)::value;
+        if (k < n) {
+            // the pivot: the largest |a_ik| among the rows at positions >= k, the smallest position among equals
+            double best = -1.0;
+            int bp = 1 << 30;
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                {
+                    const double v = fabs(a[sl][k]);
+                    const bool cand = real[sl] && pos[sl] >= k;
+                    if (cand && (v > best || (v == best && pos[sl] < bp))) {
+                        best = v;
+                        bp = pos[sl];
+                    }
+                }
+            });
+            const double m = wv::allmax16(best);
+            const double kpd = wv::allmin16((best == m && m > 0.0) ? (double)bp : 1e9);
+            const int kp = kpd < (double)n ? (int)kpd : k;
+            // its holder puts it where it belongs -- row k of the result (columns right of the diagonal are final) ...
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const bool holds = real[sl] && pos[sl] == kp;
+                if (holds)
+                    sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
+                        constexpr int g = decltype(gc)::value;
+                        wv::st2(F + k * ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
+                    });
+                // (the interchange: positions k and kp trade places)
+                pos[sl] = holds ? k : (pos[sl] == k ? kp : pos[sl]);
+            });
+            wv::wave_fence();
+            // ... and everyone reads it back
+            double b[NC];
+            sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
+                constexpr int g = decltype(gc)::value;
+                const wv::pair_t v = wv::ld2(F + k * ld + 2 * g);
+                b[2 * g] = v.lo;
+                b[2 * g + 1] = v.hi;
+            });
+            wv::wave_fence();
+            const double piv = b[k];
+            ok = ok && piv != 0.0;
+            const double inv = 1.0 / piv;
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                if (real[sl] && pos[sl] > k) {
+                    const double l = a[sl][k] * inv;
+                    a[sl][k] = l;
+                    sfor<k + 1, NC>([&](auto jc) ACME_LAMBDA {
+                        constexpr int j = decltype(jc)::value;
+                        a[sl][j] -= l * b[j];
+                    });
+                }
+                if (real[sl] && pos[sl] == k) a[sl][k] = inv;          // the reciprocal on the diagonal (src/solvers.jl:86)
+            });
+        }
+    });
+    wv::wave_fence();
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        if (real[sl]) {
+            sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
+                constexpr int g = decltype(gc)::value;
+                wv::st2(F + pos[sl] * ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
+            });
+            W[o_src + pos[sl]] = (double)(c.lig + GROUP * sl);
+        }
+    });
+    wv::wave_fence();
+    return ok;
+}
+
+// solve! with a lane's rows of the factors in registers (read once, ds_read_b128) and x_j handed round by DPP broadcasts
+// (row j of the final order sits in lane j mod 16: a compile-time lane): the 2 n sequential steps cost a broadcast and a
+// multiply-add each, where coop_lu_solve's cost an LDS read and a ds_bpermute round trip.  Same arithmetic, same order.
+template <int NC> ACME_DEV void coop_lu_solve_reg(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
+    constexpr int NS = COOP_REG_SLOTS;
+    double *W = c.W;
+    const int ld = c.H.ldf;
+    const double *F = W + o_f;
+    double f[NS][NC], xs[NS];
+    bool real[NS];
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int i = c.lig + GROUP * sl;
+        real[sl] = i < n;
+        xs[sl] = real[sl] ? W[w_x + (int)W[o_src + i]] : 0.0;
+        sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            wv::pair_t v{0.0, 0.0};
+            if (real[sl]) v = wv::ld2(F + i * ld + 2 * g);
+            f[sl][2 * g] = v.lo;
+            f[sl][2 * g + 1] = v.hi;
+        });
+    });
+    // forward: x_i -= F[i][j] x_j for i > j
+    sfor<0, NC>([&](auto jc) ACME_LAMBDA {
+        constexpr int j = decltype(jc)::value;
+        if (j < n) {
+            const double xj = wv::bcast16<j % GROUP>(xs[j / GROUP]);
+            sfor<j / GROUP, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const int i = c.lig + GROUP * sl;
+                const double t = xs[sl] - f[sl][j] * xj;
+                xs[sl] = (real[sl] && i > j) ? t : xs[sl];
+            });
+        }
+    });
+    // backward: x_j *= 1 / F[j][j] (stored), x_i -= F[i][j] x_j for i < j
+    sfor_down<NC>([&](auto jc) ACME_LAMBDA {
+        constexpr int j = decltype(jc)::value;
+        if (j < n) {
+            const double xj = wv::bcast16<j % GROUP>(f[j / GROUP][j]) * wv::bcast16<j % GROUP>(xs[j / GROUP]);
+            sfor<0, j / GROUP + 1>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const int i = c.lig + GROUP * sl;
+                const double t = xs[sl] - f[sl][j] * xj;
+                xs[sl] = i == j ? xj : (i < j ? t : xs[sl]);
+            });
+        }
+    });
+    wv::wave_fence();
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        if (real[sl]) W[w_x + c.lig + GROUP * sl] = xs[sl];
+    });
+    wv::wave_fence();
+}
+
+// the factorisation / the solve of a kernel instantiated for NC columns (0: the LDS versions, any size)
+template <int NC> ACME_DEV bool coop_factor(const CoopCtx &c, int n, int o_f, int o_src) {
+    if constexpr (NC > 0) return coop_lu_reg<NC>(c, n, o_f, o_src);
+    else return coop_lu(c, n, o_f, o_src);
+}
+template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
+    if constexpr (NC > 0) coop_lu_solve_reg<NC>(c, n, o_f, o_src, w_x);
+    else coop_lu_solve(c, n, o_f, o_src, w_x);
+}
+
 // the solver of one instance's ONE sub-problem: where its current factors / its origin's factors sit (they trade places
 // when an iterate is accepted: no copy of nn x nn doubles per sample)
 struct CoopSolver {
@@ -332,17 +508,17 @@ ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
 }
 
 // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196) at (w_lp, w_lz) for the instances with `pred`
-ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
+template <int NC> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
     coop_set_p(c, s, s.w_lp);
     (void)coop_evaluate(c, s, s.w_lz, f.o_lu);
-    (void)coop_lu(c, s.nn, f.o_lu, f.o_src);
+    (void)coop_factor<NC>(c, s.nn, f.o_lu, f.o_src);
     coop_calc_jp(c, s, s.w_ljp, pred);
     coop_accept_factors(f, pred);
 }
 
 // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`: p at w_p, z left in w_zz; returns
 // hasconverged, needediterations in its
-ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
+template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
     const GenHeader &H = c.H;
     double *W = c.W;
     const int nn = s.nn, np = s.np;
@@ -366,7 +542,7 @@ ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f
         W[H.w_tmp + r] = acc;
     }
     wv::wave_fence();
-    coop_lu_solve(c, nn, f.o_llu, f.o_lsrc, H.w_tmp);
+    coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, H.w_tmp);
     for (int r = c.lig; r < nn; r += GROUP)
         if (need) W[H.w_zz + r] = W[s.w_lz + r] - W[H.w_tmp + r];
     wv::wave_fence();
@@ -386,7 +562,7 @@ ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f
         }
         double resmax = wv::allmax16(rm);
         if (!finite) resmax = (double)NAN;
-        const bool ok = coop_lu(c, nn, f.o_lu, f.o_src);
+        const bool ok = coop_factor<NC>(c, nn, f.o_lu, f.o_src);
         COOP_T(c, CT_LU);
         const bool small = resmax < c.A.tol;
         const bool accept = act && finite && ok && small;
@@ -395,7 +571,7 @@ ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f
         // the Newton step (for everyone; only the stepping instances keep it)
         for (int r = c.lig; r < nn; r += GROUP) W[H.w_dz + r] = W[H.w_res + r];
         wv::wave_fence();
-        coop_lu_solve(c, nn, f.o_lu, f.o_src, H.w_dz);
+        coop_backsolve<NC>(c, nn, f.o_lu, f.o_src, H.w_dz);
         for (int r = c.lig; r < nn; r += GROUP)
             if (step) W[H.w_zz + r] -= W[H.w_dz + r];
         COOP_T(c, CT_SOLVE);
@@ -418,7 +594,7 @@ ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f
 }
 
 // solve(::CachingSolver, p) (src/solvers.jl:347-396) with the bounded store (lane e looks at stored solution e)
-ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
+template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
     double *W = c.W;
     const int nn = s.nn, np = s.np;
     double *cp = c.Cp;                                                                       // LDS (coop_main loads / stores it)
@@ -448,11 +624,11 @@ ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f
             for (int r = c.lig; r < nn; r += GROUP)
                 if (hit) W[s.w_lz + r] = cz[e * nn + r];
             wv::wave_fence();
-            coop_set_origin(c, s, f, hit);
+            coop_set_origin<NC>(c, s, f, hit);
         }
     }
     COOP_T(c, CT_LOOKUP);
-    const bool conv = coop_simple_solve(c, s, f, w_p, need, its);
+    const bool conv = coop_simple_solve<NC>(c, s, f, w_p, need, its);
     if (caching) {
         const bool keep = need && conv && its > 5;
         if (wv::ballot(keep) != 0ull) {
@@ -473,29 +649,31 @@ ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f
     return conv;
 }
 
-// solve(::HomotopySolver, p) (src/solvers.jl:268-296); p at w_p of the header
-ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool need0, int &its_total) {
+// solve(::HomotopySolver, p) (src/solvers.jl:268-296); p at w_p of the header.  ONE loop whose first pass is the direct
+// attempt (at w_p) and whose later passes are the bisection's (at w_pa): one inlined copy of the solver stack in the kernel
+// instead of two (what Shape::ONELOOP is to the tuned kernels: half the code for the instruction cache to hold).
+template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool need0, int &its_total) {
     const GenHeader &H = c.H;
     double *W = c.W;
-    int its;
-    bool conv = coop_cached_solve(c, s, f, H.w_p, need0, its);
-    its_total = need0 ? its : 0;
-    bool need = need0 && !conv && c.A.solver != SOLVER_SIMPLE;
-    if (wv::ballot(need) != 0ull) {
-        double a = 0.5, best = 0.0;
-        for (int j = c.lig; j < s.np; j += GROUP)
-            if (need) W[H.w_sp + j] = W[s.w_lp + j];
-        wv::wave_fence();
-        while (wv::ballot(need) != 0ull) {
-            for (int j = c.lig; j < s.np; j += GROUP) {
-                double pa = W[H.w_sp + j] * (1.0 - a);
-                pa = pa + a * W[H.w_p + j];
-                if (need) W[H.w_pa + j] = pa;
+    bool conv = false, need = need0, direct = true;
+    double a = 0.5, best = 0.0;
+    int w_src = H.w_p;
+    its_total = 0;
+    do {
+        int its;
+        const bool cv = coop_cached_solve<NC>(c, s, f, w_src, need, its);
+        its_total += need ? its : 0;
+        conv = need ? cv : conv;
+        if (direct) {
+            // the direct attempt failed for these: the homotopy starts from the origin it left behind
+            need = need && !cv && c.A.solver != SOLVER_SIMPLE;
+            direct = false;
+            if (wv::ballot(need) != 0ull) {
+                for (int j = c.lig; j < s.np; j += GROUP)
+                    if (need) W[H.w_sp + j] = W[s.w_lp + j];
+                wv::wave_fence();
             }
-            wv::wave_fence();
-            const bool cv = coop_cached_solve(c, s, f, H.w_pa, need, its);
-            its_total += need ? its : 0;
-            conv = need ? cv : conv;
+        } else {
             if (need) {
                 if (cv) {
                     best = a;
@@ -508,13 +686,21 @@ ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver 
             }
             need = need && best < 1.0;
         }
-    }
+        if (wv::ballot(need) == 0ull) break;
+        for (int j = c.lig; j < s.np; j += GROUP) {
+            double pa = W[H.w_sp + j] * (1.0 - a);
+            pa = pa + a * W[H.w_p + j];
+            if (need) W[H.w_pa + j] = pa;
+        }
+        wv::wave_fence();
+        w_src = H.w_pa;
+    } while (true);
     return conv;
 }
 
 // run! for the instances of one wave (GArgs::mode == GEN_RUN).  lds: this wave's LDS (layout above); IMGL: the batch shares
 // one model image, staged in LDS -- a dependent load from L2 costs a lone wave ~1 us, and evaluate! alone chains five of them.
-template <bool IMGL> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_global, int lane) {
+template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_global, int lane) {
     const GenHeader &H = *A.H;
     const int lig = lane & (GROUP - 1), grp = lane >> 4;
     const int gpw = A.coop_gpw;
@@ -561,7 +747,7 @@ template <bool IMGL> ACME_DEV void coop_main(const GArgs &A, double *lds, int wa
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) Cp[k] = cache_g[k];
     }
     wv::wave_fence();
-    if (has_sub) coop_set_origin(c, s, f, true);
+    if (has_sub) coop_set_origin<NC>(c, s, f, true);
     bool dead = rep[RW_FIRST_NONFINITE] >= 0;
     long long it_total = 0, it_max = 0;
     // this sample's inputs sit in LDS (GenHeader::w_u); the next sample's are requested a sample ahead (HBM latency)
@@ -596,7 +782,7 @@ template <bool IMGL> ACME_DEV void coop_main(const GArgs &A, double *lds, int wa
             wv::wave_fence();
             COOP_T(c, CT_PRE);
             int its;
-            const bool conv = coop_homotopy_solve(c, s, f, alive, its);
+            const bool conv = coop_homotopy_solve<NC>(c, s, f, alive, its);
             its_sample = alive ? its : 0;
             const bool failed = alive && !conv;
             if (wv::ballot(failed) != 0ull) {            // the policy of step! (src/ACME.jl:688-694)

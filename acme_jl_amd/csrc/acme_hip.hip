@@ -80,9 +80,10 @@ __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
 }
 
 // the mid-size kernel (acme_coop.h): one wave per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
-template <bool IMGL> __global__ __launch_bounds__(64) void acme_coop_kernel(GArgs A) {
+// (NC: the factor matrix's columns in registers -- 17 ... 32 unknowns -- or 0: factors in LDS, any size)
+template <bool IMGL, int NC> __global__ __launch_bounds__(64) void acme_coop_kernel(GArgs A) {
     extern __shared__ double acme_lds[];
-    coop_main<IMGL>(A, acme_lds, (int)blockIdx.x, (int)threadIdx.x);
+    coop_main<IMGL, NC>(A, acme_lds, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // placement of the waves by their measured cost (acme_balance.h): one thread per wave
@@ -154,18 +155,27 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)h
 static inline int launch_generic(const GArgs &A, stream_t st) {
     return ACME_LAUNCH(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
 }
-static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t st) {
-    static size_t allowed[2] = {0, 0};       // (dynamic LDS beyond 64 KB has to be asked for, once per size)
-    const bool imgl = A.coop_imgl != 0;
-    const void *fn = imgl ? (const void *)acme_coop_kernel<true> : (const void *)acme_coop_kernel<false>;
-    if (lds_bytes > allowed[imgl]) {
-        const int rc = set_max_lds(fn, (int)lds_bytes);
+template <bool IMGL, int NC> static inline int launch_coop_as(const GArgs &A, size_t lds_bytes, stream_t st) {
+    static size_t allowed = 0;               // (dynamic LDS beyond 64 KB has to be asked for, once per size)
+    if (lds_bytes > allowed) {
+        const int rc = set_max_lds((const void *)acme_coop_kernel<IMGL, NC>, (int)lds_bytes);
         if (rc != 0) return rc;
-        allowed[imgl] = lds_bytes;
+        allowed = lds_bytes;
     }
     const dim3 grid((unsigned)((A.n_inst + A.coop_gpw - 1) / A.coop_gpw));
-    if (imgl) return ACME_LAUNCH(acme_coop_kernel<true>, grid, dim3(64), lds_bytes, st, A);
-    return ACME_LAUNCH(acme_coop_kernel<false>, grid, dim3(64), lds_bytes, st, A);
+    return ACME_LAUNCH((acme_coop_kernel<IMGL, NC>), grid, dim3(64), lds_bytes, st, A);
+}
+template <bool IMGL> static inline int launch_coop_img(const GArgs &A, size_t lds_bytes, stream_t st) {
+    switch (A.coop_nc) {
+    case 20: return launch_coop_as<IMGL, 20>(A, lds_bytes, st);
+    case 24: return launch_coop_as<IMGL, 24>(A, lds_bytes, st);
+    case 28: return launch_coop_as<IMGL, 28>(A, lds_bytes, st);
+    case 32: return launch_coop_as<IMGL, 32>(A, lds_bytes, st);
+    default: return launch_coop_as<IMGL, 0>(A, lds_bytes, st);
+    }
+}
+static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t st) {
+    return A.coop_imgl != 0 ? launch_coop_img<true>(A, lds_bytes, st) : launch_coop_img<false>(A, lds_bytes, st);
 }
 static inline int launch_balance(const BalArgs &A, stream_t st) {
     const unsigned g = (unsigned)((A.nu + 255) / 256);

@@ -713,13 +713,14 @@ inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err)
     while (H.ldf % 4 != 2) ++H.ldf;
     int w = 0;
     auto wt = [&](int n) { int at = w; w += n; return at; };
+    auto wt16 = [&](int n) { w = (w + 1) & ~1; return wt(n); };      // 16-byte aligned: the factor matrices (ds_read_b128 rows)
     H.w_x = wt(m.nx); H.w_xn = wt(m.nx); H.w_z = wt(nnt);
     for (int k = 0; k < H.nsub; ++k) {
         GenSub &g = H.sub[k];
-        g.w_lp = wt(g.np); g.w_lz = wt(g.nn); g.w_ljp = wt(g.nn * g.np); g.w_llu = wt(g.nn * H.ldf); g.w_lpiv = wt(g.nn);
+        g.w_lp = wt(g.np); g.w_lz = wt(g.nn); g.w_ljp = wt(g.nn * g.np); g.w_llu = wt16(g.nn * H.ldf); g.w_lpiv = wt(g.nn);
     }
     H.w_p = wt(H.npmax); H.w_pa = wt(H.npmax); H.w_sp = wt(H.npmax); H.w_zz = wt(H.nnmax); H.w_res = wt(H.nnmax);
-    H.w_dz = wt(H.nnmax); H.w_lu = wt(H.nnmax * H.ldf); H.w_piv = wt(H.nnmax); H.w_jp = wt(H.nnmax * H.npmax);
+    H.w_dz = wt(H.nnmax); H.w_lu = wt16(H.nnmax * H.ldf); H.w_piv = wt(H.nnmax); H.w_jp = wt(H.nnmax * H.npmax);
     H.w_q = wt(H.nqmax); H.w_pf = wt(H.nqmax); H.w_tv = wt(4 * H.nnmax); H.w_tmp = wt(H.nnmax); H.w_u = wt(m.nu);
     H.ws_total = w > 0 ? w : 1;
     return true;

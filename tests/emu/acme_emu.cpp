@@ -259,8 +259,16 @@ struct CoopLaunch { const GArgs *A; double *lds; size_t per_wave; int bid; };
 static void coop_fiber_entry(void *p) {
     CoopLaunch *c = (CoopLaunch *)p;
     const int tid = wv::tid(), wave = tid >> 6;
-    if (c->A->coop_imgl != 0) coop_main<true>(*c->A, c->lds + (size_t)wave * c->per_wave, c->bid * WAVES_PER_BLOCK + wave, tid & 63);
-    else coop_main<false>(*c->A, c->lds + (size_t)wave * c->per_wave, c->bid * WAVES_PER_BLOCK + wave, tid & 63);
+    double *lds = c->lds + (size_t)wave * c->per_wave;
+    const int wg = c->bid * WAVES_PER_BLOCK + wave, lane = tid & 63;
+    const bool img = c->A->coop_imgl != 0;
+    switch (c->A->coop_nc) {
+    case 20: img ? coop_main<true, 20>(*c->A, lds, wg, lane) : coop_main<false, 20>(*c->A, lds, wg, lane); break;
+    case 24: img ? coop_main<true, 24>(*c->A, lds, wg, lane) : coop_main<false, 24>(*c->A, lds, wg, lane); break;
+    case 28: img ? coop_main<true, 28>(*c->A, lds, wg, lane) : coop_main<false, 28>(*c->A, lds, wg, lane); break;
+    case 32: img ? coop_main<true, 32>(*c->A, lds, wg, lane) : coop_main<false, 32>(*c->A, lds, wg, lane); break;
+    default: img ? coop_main<true, 0>(*c->A, lds, wg, lane) : coop_main<false, 0>(*c->A, lds, wg, lane); break;
+    }
 }
 static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t) {
     const size_t per_wave = lds_bytes / sizeof(double);

@@ -880,11 +880,17 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
             m.solver = solver
             yref, its = oracle_run(m, u, cache_limit=lim)
             outs = {}
-            for variant in ("coop", "coop, private images", "lane per instance"):
+            for variant in ("coop", "coop, private images", "coop, factors in LDS", "lane per instance"):
                 if variant == "lane per instance":
                     monkeypatch.setenv("ACME_COOP", "0")
                 else:
                     monkeypatch.delenv("ACME_COOP", raising=False)
+                # (17 ... 32 unknowns run the instantiation with the factor matrix's rows in registers; ACME_COOP_REG=0
+                # selects the any-size one with the factors in LDS, which 33 ... 64 unknowns use)
+                if "LDS" in variant:
+                    monkeypatch.setenv("ACME_COOP_REG", "0")
+                else:
+                    monkeypatch.delenv("ACME_COOP_REG", raising=False)
                 models = [m] * u.shape[0] if "private" in variant else None
                 r = ModelRunner(m, u.shape[0], lib=emu_lib, models=models)
                 assert r.kernel_family() == ("generic" if variant == "lane per instance" else "coop"), (name, variant)
@@ -894,6 +900,7 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
                 outs[variant] = y
             monkeypatch.delenv("ACME_COOP", raising=False)
             assert np.array_equal(outs["coop"], outs["coop, private images"]), name
+            assert np.array_equal(outs["coop"], outs["coop, factors in LDS"]), name
             assert np.abs(outs["coop"] - outs["lane per instance"]).max() <= 1e-13 * max(1.0, np.abs(yref).max()), name
 
 
