@@ -40,9 +40,58 @@ struct CoopTimer { long long t[CT_N]; long long mark; };
 #else
 #define COOP_T(c, b) do { } while (0)
 #endif
+#endif  // ACME_DEV
+// Where an instance's working arrays sit in its LDS workspace (doubles).  The any-size kernel (nc = 0) uses the generic
+// kernel's layout (GenHeader::w_*: every array of the solver stack, two factor matrices with a pitch of nnmax + 3 ... 6).
+// The kernels with the running factorisation in REGISTERS (nc = 20 ... 32 columns) keep only what crosses lanes or
+// samples: ONE factor matrix (the extrapolation origin's, pitch nc + 2), no Jacobian, residual, Newton step or Jq
+// non-zeros (registers), and two nc-double hand-off buffers (the pivot row of an elimination step, the x_j of a sweep) --
+// 8.8 KB per instance at 20 unknowns instead of 15.9: 16 resident instances per compute unit instead of 8, a wave for
+// every SIMD.
+struct CoopOff {
+    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, total;
+};
+ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
+    CoopOff o{};
+    const bool has_sub = H.nsub > 0;
+    if (nc == 0) {
+        o.x = H.w_x; o.xn = H.w_xn; o.z = H.w_z;
+        o.lp = has_sub ? H.sub[0].w_lp : 0; o.lz = has_sub ? H.sub[0].w_lz : 0; o.ljp = has_sub ? H.sub[0].w_ljp : 0;
+        o.llu = has_sub ? H.sub[0].w_llu : 0; o.lsrc = has_sub ? H.sub[0].w_lpiv : 0;
+        o.p = H.w_p; o.pa = H.w_pa; o.sp = H.w_sp; o.zz = H.w_zz; o.res = H.w_res; o.dz = H.w_dz; o.lu = H.w_lu; o.src = H.w_piv;
+        o.q = H.w_q; o.pf = H.w_pf; o.tv = H.w_tv; o.tmp = H.w_tmp; o.u = H.w_u; o.ld = H.ldf; o.total = H.ws_total;
+        return o;
+    }
+    const int nn = H.sub[0].nn, np = H.sub[0].np;
+    int w = 0;
+    o.ld = nc + 2;                                   // (2 mod 4 doubles: the 16 rows of a DPP row in 16 bank groups)
+    o.llu = w; w += nn * o.ld;                       // 16-byte aligned rows: offset and pitch even
+    o.prow = w; w += nc;
+    o.xb = w; w += nc;
+    o.ljp = w; w += nn * np;
+    o.lsrc = w; w += nn;
+    o.lp = w; w += np;
+    o.lz = w; w += nn;
+    o.x = w; w += H.nx;
+    o.xn = w; w += H.nx;
+    o.z = w; w += H.nnt;
+    o.p = w; w += H.npmax;
+    o.pa = w; w += H.npmax;
+    o.sp = w; w += H.npmax;
+    o.zz = w; w += H.nnmax;
+    o.q = w; w += H.nqmax;
+    o.pf = w; w += H.nqmax;
+    o.tmp = w; w += H.nnmax;
+    o.u = w; w += H.nu;
+    o.res = o.dz = o.lu = o.src = o.tv = 0;          // (registers)
+    o.total = w;
+    return o;
+}
+#ifdef ACME_DEV
 struct CoopCtx {
     const GArgs &A;
     const GenHeader &H;
+    const CoopOff &O;
     const double *M;         // this instance's image: the block's copy in LDS (a shared image) or HBM (private images)
     double *W;               // this instance's workspace in LDS: the generic kernel's offsets (GenHeader::w_*)
     double *Cp;              // ... and its solution cache's stored p's and counters: cp[np][CACHE] | count, head (LDS)
@@ -61,7 +110,7 @@ ACME_HD inline int coop_table_doubles(const GenHeader &H) {
     return blocks * (8 * GROUP + ROWI * GROUP / 2);
 }
 ACME_HD inline int coop_cache_doubles(const GenHeader &H) { return H.nsub > 0 ? ((H.sub[0].np * CACHE + 2 + 1) & ~1) : 0; }
-ACME_HD inline int coop_inst_doubles(const GenHeader &H) { return ((H.ws_total + 1) & ~1) + coop_cache_doubles(H); }
+ACME_HD inline int coop_inst_doubles(const GenHeader &H, int nc) { return ((coop_offsets(H, nc).total + 1) & ~1) + coop_cache_doubles(H); }
 ACME_HD inline int coop_shared_doubles(const GenHeader &H, bool shared_image) {
     return (shared_image ? ((H.image_total + 1) & ~1) : 0) + coop_table_doubles(H);
 }
@@ -103,7 +152,7 @@ ACME_DEV void coop_rowdesc(const CoopCtx &c, int R, RowDesc &rd, int (&tc)[4]) {
 // pfull <- q0 + pexp p  (set_p closure, src/ACME.jl:237-243); p at w_p must be visible (fenced)
 ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
     for (int r = c.lig; r < s.nq; r += GROUP) {
-        c.W[c.H.w_pf + r] = coop_dot(c.M + s.o_pexp + r, s.nq, c.W + w_p, s.np, c.M[s.o_q0 + r]);
+        c.W[c.O.pf + r] = coop_dot(c.M + s.o_pexp + r, s.nq, c.W + w_p, s.np, c.M[s.o_q0 + r]);
     }
     wv::wave_fence();
 }
@@ -114,7 +163,7 @@ ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
 ACME_DEV bool coop_evaluate(const CoopCtx &c, const GenSub &s, int w_z, int o_lu) {
     const GenHeader &H = c.H;
     for (int r = c.lig; r < s.nq; r += GROUP) {
-        c.W[H.w_q + r] = coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[H.w_pf + r]);
+        c.W[c.O.q + r] = coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
     bool bad = false;
@@ -124,14 +173,14 @@ ACME_DEV bool coop_evaluate(const CoopCtx &c, const GenSub &s, int w_z, int o_lu
         int tc[4];
         coop_rowdesc(c, s.row0 + r, rd, tc);
         double e[4], tv[4], res;
-        for (int t = 0; t < 4; ++t) e[t] = c.W[H.w_q + tc[t]];
+        for (int t = 0; t < 4; ++t) e[t] = c.W[c.O.q + tc[t]];
         const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
         const double exA = exp_junction(expo ? e[0] * rd.k[0] : 0.0, etab);
         const double exB = H.has_bjt ? exp_junction(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0, etab) : 1.0;
         eval_row<true, 4>(rd, e, exA, exB, res, tv);
-        c.W[H.w_res + r] = res;
+        c.W[c.O.res + r] = res;
         bad = bad || !(res * 0.0 == 0.0);
-        for (int t = 0; t < 4; ++t) c.W[H.w_tv + 4 * r + t] = tv[t];
+        for (int t = 0; t < 4; ++t) c.W[c.O.tv + 4 * r + t] = tv[t];
         for (int j = 0; j < s.nn; j += 4) {         // J row = Jq row * fq, four columns' operands at a time
             double fv[4][4];
             for (int u = 0; u < 4; ++u) {
@@ -159,7 +208,7 @@ ACME_DEV void coop_calc_jp(const CoopCtx &c, const GenSub &s, int w_dst, bool pr
         int tc[4];
         coop_rowdesc(c, s.row0 + r, rd, tc);
         double tv[4];
-        for (int t = 0; t < 4; ++t) tv[t] = c.W[H.w_tv + 4 * r + t];
+        for (int t = 0; t < 4; ++t) tv[t] = c.W[c.O.tv + 4 * r + t];
         for (int j = 0; j < s.np; j += 4) {
             double pv[4][4];
             for (int u = 0; u < 4; ++u) {
@@ -186,7 +235,7 @@ ACME_DEV void coop_calc_jp(const CoopCtx &c, const GenSub &s, int w_dst, bool pr
 // version spent 12 instructions per multiply-add and 135 000 cycles per sample in here, at 20 unknowns.)
 ACME_DEV bool coop_lu(const CoopCtx &c, int n, int o_f, int o_src) {
     double *W = c.W;
-    const int ld = c.H.ldf;
+    const int ld = c.O.ld;
     for (int i = c.lig; i < n; i += GROUP) W[o_src + i] = (double)i;
     wv::wave_fence();
     bool ok = true;
@@ -256,7 +305,7 @@ ACME_DEV bool coop_lu(const CoopCtx &c, int n, int o_f, int o_src) {
 // registers became an array in scratch memory, a memory round trip per step.)
 ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
     double *W = c.W;
-    const int ld = c.H.ldf;
+    const int ld = c.O.ld;
     const int ns = (n + GROUP - 1) / GROUP;          // slots in use (uniform): the others' code is skipped, not predicated
     double xs[COOP_SLOTS];
     sfor<0, COOP_SLOTS>([&](auto sc) ACME_LAMBDA {
@@ -317,40 +366,111 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
     wv::wave_fence();
 }
 
-// ---- the factor matrix in REGISTERS (17 ... 32 unknowns: kernels instantiated per NC = the unknowns rounded up to 4) ----
-// The LDS version above walks the elimination through LDS: per step a pivot search, an interchange and an update, each a
-// round trip of LDS latency that a lone wave has nothing to hide behind (96 000 of 187 000 cycles per sample at 20 unknowns).
-// Here a lane reads its (up to two) rows ONCE (ds_read_b128), keeps them in registers through all n steps -- column indices
-// are compile-time constants, the step loop is written out -- and writes the factors once.  A row never moves: the
-// reference's full-row interchange becomes the row's POSITION label (pos: where the row would sit after the interchanges so
-// far), which is what decides a tie in the pivot search (first strict maximum = the smallest position) and where the row is
-// written at the end; the step's pivot row travels through LDS row k of the result (its final place), one write by its
-// holder and one broadcast read by everyone.  Arithmetic per entry: unchanged (l = a_ik * (1 / a_kk), a_ij -= l a_kj in
-// the order k = 0, 1, ...), so the factors, the gather and the zero-pivot verdict are coop_lu's bit for bit.
+// ---- the running factorisation in REGISTERS (17 ... 32 unknowns: kernels instantiated per NC = the unknowns rounded up to 4) ----
+// The any-size path above walks evaluate! -> setlhs! -> solve! through LDS: every elimination step is a pivot search, an
+// interchange and an update with LDS round trips a lone wave has nothing to hide behind (96 000 of 187 000 cycles per sample
+// at 20 unknowns), and the two factor matrices are half of an instance's 16 KB -- 8 instances per compute unit, two waves,
+// two of four SIMDs idle.  Here a lane computes its (up to two) Jacobian rows INTO registers, keeps them there through
+// all n elimination steps (column indices are compile-time constants, the step loop is written out) and through the Newton
+// step's triangular sweeps; only an ACCEPTED iterate's factors go to LDS (the extrapolation origin's matrix, the one
+// factor matrix an instance keeps).  A row never moves: the reference's full-row interchange becomes the row's POSITION
+// label (pos: where the row would sit after the interchanges so far) -- it decides a tie in the pivot search (first strict
+// maximum = the smallest position), tells the sweeps their order, and says where the row is written on acceptance.  What
+// crosses lanes goes through two small LDS buffers: a step's pivot row (written by its holder, read by everyone) and a
+// sweep's x_j.  Arithmetic per entry: unchanged (l = a_ik * (1 / a_kk), a_ij -= l a_kj in the order k = 0, 1, ...;
+// x_i -= F_ij x_j in the order of j), so factors, gather, zero-pivot verdict and solutions are the LDS path's bit for bit.
 constexpr int COOP_REG_SLOTS = 2;
-template <int NC> ACME_DEV bool coop_lu_reg(const CoopCtx &c, int n, int o_f, int o_src) {
+
+// evaluate!(nleq, z) as coop_evaluate, the rows' residuals, Jacobian rows (columns >= nn: zero) and Jq non-zeros in registers
+template <int NC>
+ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, double (&a)[COOP_REG_SLOTS][NC],
+                                 double (&res)[COOP_REG_SLOTS], double (&tvr)[COOP_REG_SLOTS][4]) {
+    constexpr int NS = COOP_REG_SLOTS;
+    const GenHeader &H = c.H;
+    for (int r = c.lig; r < s.nq; r += GROUP) {
+        c.W[c.O.q + r] = coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
+    }
+    wv::wave_fence();
+    bool bad = false;
+    const wv::ExpTab etab = wv::load_exp_tab();
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int r = c.lig + GROUP * sl;
+        res[sl] = 0.0;
+        for (int t = 0; t < 4; ++t) tvr[sl][t] = 0.0;
+        sfor<0, NC>([&](auto jc) ACME_LAMBDA { a[sl][decltype(jc)::value] = 0.0; });
+        if (r < s.nn) {
+            RowDesc rd;
+            int tc[4];
+            coop_rowdesc(c, s.row0 + r, rd, tc);
+            double e[4], tv[4], rs;
+            for (int t = 0; t < 4; ++t) e[t] = c.W[c.O.q + tc[t]];
+            const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
+            const double exA = exp_junction(expo ? e[0] * rd.k[0] : 0.0, etab);
+            const double exB = H.has_bjt ? exp_junction(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0, etab) : 1.0;
+            eval_row<true, 4>(rd, e, exA, exB, rs, tv);
+            res[sl] = rs;
+            bad = bad || !(rs * 0.0 == 0.0);
+            for (int t = 0; t < 4; ++t) tvr[sl][t] = tv[t];
+            sfor<0, NC / 4>([&](auto gc) ACME_LAMBDA {          // J row = Jq row * fq, four columns' operands at a time
+                constexpr int j = 4 * decltype(gc)::value;
+                double fv[4][4];
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u < s.nn ? j + u : s.nn - 1;
+                    for (int t = 0; t < 4; ++t) fv[u][t] = c.M[s.o_fq + jj * s.nq + tc[t]];
+                }
+                sfor<0, 4>([&](auto uc) ACME_LAMBDA {
+                    constexpr int u = decltype(uc)::value;
+                    double acc = 0.0;
+                    for (int t = 0; t < 4; ++t) acc = fma(tv[t], fv[u][t], acc);
+                    const bool col = j + u < s.nn;
+                    a[sl][j + u] = col ? acc : 0.0;
+                    bad = bad || (col && !(acc * 0.0 == 0.0));
+                });
+            });
+        }
+    });
+    return bad;
+}
+
+// calc_Jp closure with the Jq non-zeros of the latest coop_evaluate_rows, written to the origin's Jp where `pred`
+ACME_DEV void coop_calc_jp_rows(const CoopCtx &c, const GenSub &s, const double (&tvr)[COOP_REG_SLOTS][4], bool pred) {
+    sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int r = c.lig + GROUP * sl;
+        if (r < s.nn) {
+            const int blk = (s.row0 + r) / GROUP, ln = (s.row0 + r) % GROUP;
+            int tc[4];
+            for (int t = 0; t < 4; ++t) tc[t] = c.ti[blk * ROWI * GROUP + (3 + t) * GROUP + ln];
+            for (int j = 0; j < s.np; j += 4) {
+                double pv[4][4];
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u < s.np ? j + u : s.np - 1;
+                    for (int t = 0; t < 4; ++t) pv[u][t] = c.M[s.o_pexp + jj * s.nq + tc[t]];
+                }
+                for (int u = 0; u < 4; ++u) {
+                    double acc = 0.0;
+                    for (int t = 0; t < 4; ++t) acc = fma(tvr[sl][t], pv[u][t], acc);
+                    if (pred && j + u < s.np) c.W[c.O.ljp + (j + u) * s.nn + r] = acc;
+                }
+            }
+        }
+    });
+    wv::wave_fence();
+}
+
+// setlhs! on the rows in registers; pos: the rows' positions in the factored matrix.  Returns false for the instances that
+// met an exactly zero pivot.
+template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][NC], int (&pos)[COOP_REG_SLOTS]) {
     static_assert(NC % 4 == 0 && NC <= GROUP * COOP_REG_SLOTS, "columns in pairs, two rows per lane");
     constexpr int NS = COOP_REG_SLOTS;
-    double *W = c.W;
-    const int ld = c.H.ldf;
-    double *F = W + o_f;                      // 16-byte aligned rows (even offset, even pitch: acme_pack.h)
-    double a[NS][NC];
-    int pos[NS];
+    double *P = c.W + c.O.prow;               // the step's pivot row (16-byte aligned)
     bool real[NS];
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int i = c.lig + GROUP * sl;
-        real[sl] = i < n;
-        pos[sl] = i;
-        sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
-            constexpr int g = decltype(gc)::value;
-            wv::pair_t v{0.0, 0.0};
-            if (real[sl]) v = wv::ld2(F + i * ld + 2 * g);
-            a[sl][2 * g] = v.lo;
-            a[sl][2 * g + 1] = v.hi;
-        });
+        pos[sl] = c.lig + GROUP * sl;
+        real[sl] = pos[sl] < n;
     });
-    wv::wave_fence();
     bool ok = true;
     sfor<0, NC>([&](auto kc) ACME_LAMBDA {
         constexpr int k = decltype(kc)::value;
@@ -360,43 +480,45 @@ template <int NC> ACME_DEV bool coop_lu_reg(const CoopCtx &c, int n, int o_f, in
             int bp = 1 << 30;
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                {
-                    const double v = fabs(a[sl][k]);
-                    const bool cand = real[sl] && pos[sl] >= k;
-                    if (cand && (v > best || (v == best && pos[sl] < bp))) {
-                        best = v;
-                        bp = pos[sl];
-                    }
+                const double v = fabs(a[sl][k]);
+                const bool cand = real[sl] && pos[sl] >= k;
+                if (cand && (v > best || (v == best && pos[sl] < bp))) {
+                    best = v;
+                    bp = pos[sl];
                 }
             });
             const double m = wv::allmax16(best);
+            // |pivot| is known here, its sign only after the row has come round: the division (a dozen dependent
+            // operations) runs beside the second reduction and the LDS round trip instead of behind them
+            const double inv_abs = 1.0 / m;
             const double kpd = wv::allmin16((best == m && m > 0.0) ? (double)bp : 1e9);
             const int kp = kpd < (double)n ? (int)kpd : k;
-            // its holder puts it where it belongs -- row k of the result (columns right of the diagonal are final) ...
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
                 const bool holds = real[sl] && pos[sl] == kp;
                 if (holds)
                     sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
                         constexpr int g = decltype(gc)::value;
-                        wv::st2(F + k * ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
+                        wv::st2(P + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
                     });
                 // (the interchange: positions k and kp trade places)
                 pos[sl] = holds ? k : (pos[sl] == k ? kp : pos[sl]);
             });
-            wv::wave_fence();
-            // ... and everyone reads it back
+            wv::lds_order();
             double b[NC];
             sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
                 constexpr int g = decltype(gc)::value;
-                const wv::pair_t v = wv::ld2(F + k * ld + 2 * g);
+                const wv::pair_t v = wv::ld2(P + 2 * g);
                 b[2 * g] = v.lo;
                 b[2 * g + 1] = v.hi;
             });
-            wv::wave_fence();
             const double piv = b[k];
             ok = ok && piv != 0.0;
-            const double inv = 1.0 / piv;
+            double inv = copysign(inv_abs, piv);
+            if (wv::ballot(!(m > 0.0)) != 0ull) {          // no pivot candidate (a zero or NaN column): the reference's 1 / a_kk
+                const double direct = 1.0 / piv;
+                inv = m > 0.0 ? inv : direct;
+            }
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
                 if (real[sl] && pos[sl] > k) {
@@ -411,19 +533,72 @@ template <int NC> ACME_DEV bool coop_lu_reg(const CoopCtx &c, int n, int o_f, in
             });
         }
     });
-    wv::wave_fence();
-    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+    return ok;
+}
+
+// solve! with the factors as coop_lu_rows left them (rows in their lanes, positions in pos).  xs: in, the right-hand side
+// of the lane's rows (x_permuted[pos] = x[row]: the gather is the layout); out, the solution's entry number pos of each row.
+// A sweep's x_j comes from whichever lane holds position j: it writes it to LDS, everyone reads it.
+template <int NC>
+ACME_DEV void coop_solve_rows(const CoopCtx &c, int n, const double (&a)[COOP_REG_SLOTS][NC], const int (&pos)[COOP_REG_SLOTS],
+                              double (&xs)[COOP_REG_SLOTS]) {
+    constexpr int NS = COOP_REG_SLOTS;
+    double *X = c.W + c.O.xb;
+    bool real[NS];
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA { real[decltype(sc)::value] = c.lig + GROUP * decltype(sc)::value < n; });
+    // forward: x_i -= F[i][j] x_j for i > j
+    sfor<0, NC>([&](auto jc) ACME_LAMBDA {
+        constexpr int j = decltype(jc)::value;
+        if (j < n) {
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                if (real[sl] && pos[sl] == j) X[j] = xs[sl];
+            });
+            wv::lds_order();
+            const double xj = X[j];
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const double t = xs[sl] - a[sl][j] * xj;
+                xs[sl] = (real[sl] && pos[sl] > j) ? t : xs[sl];
+            });
+        }
+    });
+    // backward: x_j *= 1 / F[j][j] (stored), x_i -= F[i][j] x_j for i < j
+    sfor_down<NC>([&](auto jc) ACME_LAMBDA {
+        constexpr int j = decltype(jc)::value;
+        if (j < n) {
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                if (real[sl] && pos[sl] == j) X[j] = a[sl][j] * xs[sl];
+            });
+            wv::lds_order();
+            const double xj = X[j];
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const double t = xs[sl] - a[sl][j] * xj;
+                xs[sl] = pos[sl] == j ? xj : ((real[sl] && pos[sl] < j) ? t : xs[sl]);
+            });
+        }
+    });
+}
+
+// an accepted iterate's factors into the origin's matrix in LDS, every row at its position, with the gather solve! starts
+// from (src[position] = row) -- what coop_lu leaves behind, for the instances with `pred`
+template <int NC>
+ACME_DEV void coop_store_factors(const CoopCtx &c, int n, const double (&a)[COOP_REG_SLOTS][NC], const int (&pos)[COOP_REG_SLOTS], bool pred) {
+    double *F = c.W + c.O.llu;
+    sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        if (real[sl]) {
+        const int i = c.lig + GROUP * sl;
+        if (pred && i < n) {
             sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
                 constexpr int g = decltype(gc)::value;
-                wv::st2(F + pos[sl] * ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
+                wv::st2(F + pos[sl] * c.O.ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
             });
-            W[o_src + pos[sl]] = (double)(c.lig + GROUP * sl);
+            c.W[c.O.lsrc + pos[sl]] = (double)i;
         }
     });
     wv::wave_fence();
-    return ok;
 }
 
 // solve! with a lane's rows of the factors in registers (read once, ds_read_b128) and x_j handed round by DPP broadcasts
@@ -432,7 +607,7 @@ template <int NC> ACME_DEV bool coop_lu_reg(const CoopCtx &c, int n, int o_f, in
 template <int NC> ACME_DEV void coop_lu_solve_reg(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
     constexpr int NS = COOP_REG_SLOTS;
     double *W = c.W;
-    const int ld = c.H.ldf;
+    const int ld = c.O.ld;
     const double *F = W + o_f;
     double f[NS][NC], xs[NS];
     bool real[NS];
@@ -483,11 +658,7 @@ template <int NC> ACME_DEV void coop_lu_solve_reg(const CoopCtx &c, int n, int o
     wv::wave_fence();
 }
 
-// the factorisation / the solve of a kernel instantiated for NC columns (0: the LDS versions, any size)
-template <int NC> ACME_DEV bool coop_factor(const CoopCtx &c, int n, int o_f, int o_src) {
-    if constexpr (NC > 0) return coop_lu_reg<NC>(c, n, o_f, o_src);
-    else return coop_lu(c, n, o_f, o_src);
-}
+// the extrapolation's solve! of a kernel instantiated for NC columns (0: the LDS version, any size)
 template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
     if constexpr (NC > 0) coop_lu_solve_reg<NC>(c, n, o_f, o_src, w_x);
     else coop_lu_solve(c, n, o_f, o_src, w_x);
@@ -509,11 +680,20 @@ ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
 
 // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196) at (w_lp, w_lz) for the instances with `pred`
 template <int NC> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
-    coop_set_p(c, s, s.w_lp);
-    (void)coop_evaluate(c, s, s.w_lz, f.o_lu);
-    (void)coop_factor<NC>(c, s.nn, f.o_lu, f.o_src);
-    coop_calc_jp(c, s, s.w_ljp, pred);
-    coop_accept_factors(f, pred);
+    coop_set_p(c, s, c.O.lp);
+    if constexpr (NC > 0) {
+        double a[COOP_REG_SLOTS][NC], res[COOP_REG_SLOTS], tv[COOP_REG_SLOTS][4];
+        int pos[COOP_REG_SLOTS];
+        (void)coop_evaluate_rows<NC>(c, s, c.O.lz, a, res, tv);
+        (void)coop_lu_rows<NC>(c, s.nn, a, pos);
+        coop_calc_jp_rows(c, s, tv, pred);
+        coop_store_factors<NC>(c, s.nn, a, pos, pred);
+    } else {
+        (void)coop_evaluate(c, s, c.O.lz, f.o_lu);
+        (void)coop_lu(c, s.nn, f.o_lu, f.o_src);
+        coop_calc_jp(c, s, c.O.ljp, pred);
+        coop_accept_factors(f, pred);
+    }
 }
 
 // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`: p at w_p, z left in w_zz; returns
@@ -532,62 +712,110 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             double jv[COOP_B], pv[COOP_B], lv[COOP_B];
             for (int u = 0; u < COOP_B; ++u) {
                 const int jj = j + u < np ? j + u : np - 1;
-                jv[u] = W[s.w_ljp + jj * nn + r];
+                jv[u] = W[c.O.ljp + jj * nn + r];
                 pv[u] = W[w_p + jj];
-                lv[u] = W[s.w_lp + jj];
+                lv[u] = W[c.O.lp + jj];
             }
             for (int u = 0; u < COOP_B; ++u)
                 if (j + u < np) acc = fma(jv[u], pv[u] - lv[u], acc);
         }
-        W[H.w_tmp + r] = acc;
+        W[c.O.tmp + r] = acc;
     }
     wv::wave_fence();
-    coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, H.w_tmp);
+    coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
     for (int r = c.lig; r < nn; r += GROUP)
-        if (need) W[H.w_zz + r] = W[s.w_lz + r] - W[H.w_tmp + r];
+        if (need) W[c.O.zz + r] = W[c.O.lz + r] - W[c.O.tmp + r];
     wv::wave_fence();
     COOP_T(c, CT_EXTRAP);
     bool act = need, conv = false;
     double reslast = 0.0;
     its = 0;
-    while (wv::ballot(act) != 0ull) {
-        its += act ? 1 : 0;
-        const bool bad = coop_evaluate(c, s, H.w_zz, f.o_lu);
-        COOP_T(c, CT_EVAL);
-        const bool finite = !coop_any(c, bad);
-        double rm = 0.0;
-        for (int r = c.lig; r < nn; r += GROUP) {
-            const double v = fabs(W[H.w_res + r]);
-            if (v > rm) rm = v;
+    if constexpr (NC > 0) {
+        constexpr int NS = COOP_REG_SLOTS;
+        while (wv::ballot(act) != 0ull) {
+            its += act ? 1 : 0;
+            double a[NS][NC], res[NS], tv[NS][4];
+            int pos[NS];
+            const bool bad = coop_evaluate_rows<NC>(c, s, c.O.zz, a, res, tv);
+            COOP_T(c, CT_EVAL);
+            const bool finite = !coop_any(c, bad);
+            double rm = 0.0;
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const double v = fabs(res[sl]);
+                if (c.lig + GROUP * sl < nn && v > rm) rm = v;
+            });
+            double resmax = wv::allmax16(rm);
+            if (!finite) resmax = (double)NAN;
+            const bool ok = coop_lu_rows<NC>(c, nn, a, pos);
+            COOP_T(c, CT_LU);
+            const bool small = resmax < c.A.tol;
+            const bool accept = act && finite && ok && small;
+            const bool step = act && finite && ok && !small;
+            reslast = act ? resmax : reslast;
+            // the Newton step, straight from the registers (skipped when the whole wave is done stepping)
+            if (wv::ballot(step) != 0ull) {
+                coop_solve_rows<NC>(c, nn, a, pos, res);
+                sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                    constexpr int sl = decltype(sc)::value;
+                    if (step && c.lig + GROUP * sl < nn) W[c.O.zz + pos[sl]] -= res[sl];
+                });
+            }
+            COOP_T(c, CT_SOLVE);
+            // an accepted iterate: its factors, Jp, p and z become the extrapolation origin
+            if (wv::ballot(accept) != 0ull) {
+                coop_calc_jp_rows(c, s, tv, accept);
+                coop_store_factors<NC>(c, nn, a, pos, accept);
+                for (int j = c.lig; j < np; j += GROUP)
+                    if (accept) W[c.O.lp + j] = W[w_p + j];
+                for (int r = c.lig; r < nn; r += GROUP)
+                    if (accept) W[c.O.lz + r] = W[c.O.zz + r];
+            }
+            wv::wave_fence();
+            COOP_T(c, CT_ACCEPT);
+            conv = conv || accept;
+            act = step && its < c.A.maxiter;
         }
-        double resmax = wv::allmax16(rm);
-        if (!finite) resmax = (double)NAN;
-        const bool ok = coop_factor<NC>(c, nn, f.o_lu, f.o_src);
-        COOP_T(c, CT_LU);
-        const bool small = resmax < c.A.tol;
-        const bool accept = act && finite && ok && small;
-        const bool step = act && finite && ok && !small;
-        reslast = act ? resmax : reslast;
-        // the Newton step (for everyone; only the stepping instances keep it)
-        for (int r = c.lig; r < nn; r += GROUP) W[H.w_dz + r] = W[H.w_res + r];
-        wv::wave_fence();
-        coop_backsolve<NC>(c, nn, f.o_lu, f.o_src, H.w_dz);
-        for (int r = c.lig; r < nn; r += GROUP)
-            if (step) W[H.w_zz + r] -= W[H.w_dz + r];
-        COOP_T(c, CT_SOLVE);
-        // an accepted iterate: its factors, Jp, p and z become the extrapolation origin
-        if (wv::ballot(accept) != 0ull) {
-            coop_calc_jp(c, s, s.w_ljp, accept);
-            coop_accept_factors(f, accept);
-            for (int j = c.lig; j < np; j += GROUP)
-                if (accept) W[s.w_lp + j] = W[w_p + j];
+    } else {
+        while (wv::ballot(act) != 0ull) {
+            its += act ? 1 : 0;
+            const bool bad = coop_evaluate(c, s, c.O.zz, f.o_lu);
+            COOP_T(c, CT_EVAL);
+            const bool finite = !coop_any(c, bad);
+            double rm = 0.0;
+            for (int r = c.lig; r < nn; r += GROUP) {
+                const double v = fabs(W[c.O.res + r]);
+                if (v > rm) rm = v;
+            }
+            double resmax = wv::allmax16(rm);
+            if (!finite) resmax = (double)NAN;
+            const bool ok = coop_lu(c, nn, f.o_lu, f.o_src);
+            COOP_T(c, CT_LU);
+            const bool small = resmax < c.A.tol;
+            const bool accept = act && finite && ok && small;
+            const bool step = act && finite && ok && !small;
+            reslast = act ? resmax : reslast;
+            // the Newton step (for everyone; only the stepping instances keep it)
+            for (int r = c.lig; r < nn; r += GROUP) W[c.O.dz + r] = W[c.O.res + r];
+            wv::wave_fence();
+            coop_backsolve<NC>(c, nn, f.o_lu, f.o_src, c.O.dz);
             for (int r = c.lig; r < nn; r += GROUP)
-                if (accept) W[s.w_lz + r] = W[H.w_zz + r];
+                if (step) W[c.O.zz + r] -= W[c.O.dz + r];
+            COOP_T(c, CT_SOLVE);
+            // an accepted iterate: its factors, Jp, p and z become the extrapolation origin
+            if (wv::ballot(accept) != 0ull) {
+                coop_calc_jp(c, s, c.O.ljp, accept);
+                coop_accept_factors(f, accept);
+                for (int j = c.lig; j < np; j += GROUP)
+                    if (accept) W[c.O.lp + j] = W[w_p + j];
+                for (int r = c.lig; r < nn; r += GROUP)
+                    if (accept) W[c.O.lz + r] = W[c.O.zz + r];
+            }
+            wv::wave_fence();
+            COOP_T(c, CT_ACCEPT);
+            conv = conv || accept;
+            act = step && its < c.A.maxiter;
         }
-        wv::wave_fence();
-        COOP_T(c, CT_ACCEPT);
-        conv = conv || accept;
-        act = step && its < c.A.maxiter;
     }
     (void)conv;
     return reslast < c.A.tol;          // hasconverged (:203): false for a NaN residual
@@ -607,7 +835,7 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
         const int count = c.valid ? meta[0] : 0;
         for (int j = 0; j < np; ++j) {
             const double pj = W[w_p + j];
-            const double dl = pj - W[s.w_lp + j];
+            const double dl = pj - W[c.O.lp + j];
             best = fma(dl, dl, best);
             const double t = (c.valid ? cp[j * CACHE + c.lig] : 0.0) - pj;
             d = fma(t, t, d);
@@ -620,9 +848,9 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
         if (wv::ballot(hit) != 0ull) {
             const int e = hit ? idx : 0;
             for (int j = c.lig; j < np; j += GROUP)
-                if (hit) W[s.w_lp + j] = cp[j * CACHE + e];
+                if (hit) W[c.O.lp + j] = cp[j * CACHE + e];
             for (int r = c.lig; r < nn; r += GROUP)
-                if (hit) W[s.w_lz + r] = cz[e * nn + r];
+                if (hit) W[c.O.lz + r] = cz[e * nn + r];
             wv::wave_fence();
             coop_set_origin<NC>(c, s, f, hit);
         }
@@ -638,7 +866,7 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
             for (int j = c.lig; j < np; j += GROUP)
                 if (keep) cp[j * CACHE + slot] = W[w_p + j];
             for (int r = c.lig; r < nn; r += GROUP)
-                if (keep) cz[slot * nn + r] = W[c.H.w_zz + r];
+                if (keep) cz[slot * nn + r] = W[c.O.zz + r];
             if (keep && c.lig == 0) {
                 meta[0] = count < CACHE ? count + 1 : count;
                 meta[1] = count < CACHE ? head : (head + 1) & (CACHE - 1);
@@ -657,7 +885,7 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
     double *W = c.W;
     bool conv = false, need = need0, direct = true;
     double a = 0.5, best = 0.0;
-    int w_src = H.w_p;
+    int w_src = c.O.p;
     its_total = 0;
     do {
         int its;
@@ -670,7 +898,7 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
             direct = false;
             if (wv::ballot(need) != 0ull) {
                 for (int j = c.lig; j < s.np; j += GROUP)
-                    if (need) W[H.w_sp + j] = W[s.w_lp + j];
+                    if (need) W[c.O.sp + j] = W[c.O.lp + j];
                 wv::wave_fence();
             }
         } else {
@@ -688,12 +916,12 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
         }
         if (wv::ballot(need) == 0ull) break;
         for (int j = c.lig; j < s.np; j += GROUP) {
-            double pa = W[H.w_sp + j] * (1.0 - a);
-            pa = pa + a * W[H.w_p + j];
-            if (need) W[H.w_pa + j] = pa;
+            double pa = W[c.O.sp + j] * (1.0 - a);
+            pa = pa + a * W[c.O.p + j];
+            if (need) W[c.O.pa + j] = pa;
         }
         wv::wave_fence();
-        w_src = H.w_pa;
+        w_src = c.O.pa;
     } while (true);
     return conv;
 }
@@ -722,9 +950,10 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     const bool valid = grp < gpw && slot < A.n_inst;
     if (!valid) return;      // (a row of 16 lanes without an instance leaves: nothing below crosses the rows of a wave)
     const long long i = slot;
-    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)grp * coop_inst_doubles(H);
-    double *Cp = W + ((H.ws_total + 1) & ~1);
-    CoopCtx c{A, H, IMGL ? img : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid};
+    const CoopOff O = coop_offsets(H, NC);
+    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)grp * coop_inst_doubles(H, NC);
+    double *Cp = W + ((O.total + 1) & ~1);
+    CoopCtx c{A, H, O, IMGL ? img : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid};
 #ifdef ACME_COOP_TIMING
     CoopTimer tmr{};
     tmr.mark = (long long)__builtin_readcyclecounter();
@@ -734,15 +963,15 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     long long *rep = A.report + i * RW_WORDS;
     const bool has_sub = H.nsub > 0;
     const GenSub &s = H.sub[0];
-    CoopSolver f{H.w_lu, H.w_piv, has_sub ? s.w_llu : 0, has_sub ? s.w_lpiv : 0};
+    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0};
     const bool caching = has_sub && A.solver == SOLVER_CACHING_HOMOTOPY;
     double *cache_g = A.cache + i * H.cache_total + (has_sub ? s.c_off : 0);
-    for (int k = lig; k < H.ws_total; k += GROUP) W[k] = 0.0;
+    for (int k = lig; k < O.total; k += GROUP) W[k] = 0.0;
     wv::wave_fence();
-    for (int k = lig; k < H.nx; k += GROUP) W[H.w_x + k] = st[k];
+    for (int k = lig; k < H.nx; k += GROUP) W[c.O.x + k] = st[k];
     if (has_sub) {
-        for (int j = lig; j < s.np; j += GROUP) W[s.w_lp + j] = st[H.nx + s.poff + j];
-        for (int r = lig; r < s.nn; r += GROUP) W[s.w_lz + r] = st[H.nx + H.npt + s.zoff + r];
+        for (int j = lig; j < s.np; j += GROUP) W[c.O.lp + j] = st[H.nx + s.poff + j];
+        for (int r = lig; r < s.nn; r += GROUP) W[c.O.lz + r] = st[H.nx + H.npt + s.zoff + r];
         if (caching)       // the stored p's and the two counters live in LDS for the launch
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) Cp[k] = cache_g[k];
     }
@@ -761,23 +990,23 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         // inputs of this sample into LDS, the next sample's requested
         for (int sl = 0; sl < COOP_SLOTS; ++sl) {
             const int k = lig + GROUP * sl;
-            if (k < H.nu) W[H.w_u + k] = upre[sl];
+            if (k < H.nu) W[c.O.u + k] = upre[sl];
         }
         wv::wave_fence();
         for (int sl = 0; sl < COOP_SLOTS; ++sl) {
             const int k = lig + GROUP * sl;
             if (k < H.nu && n + 1 < A.T) upre[sl] = A.u[(i * A.T + n + 1) * H.nu + k];
         }
-        const double *un = W + H.w_u;
+        const double *un = W + c.O.u;
         COOP_T(c, CT_REST);
         const bool alive = !dead;
         long long its_sample = 0;
         if (has_sub) {
             // p = dq x + eq u  (src/ACME.jl:678-683; a first sub-problem has no fqprev term)
             for (int r = lig; r < s.np; r += GROUP) {
-                double acc = coop_dot(c.M + s.o_dq + r, s.np, W + H.w_x, H.nx, 0.0);
+                double acc = coop_dot(c.M + s.o_dq + r, s.np, W + c.O.x, H.nx, 0.0);
                 acc = coop_dot(c.M + s.o_eq + r, s.np, un, H.nu, acc);
-                if (alive) W[H.w_p + r] = acc;
+                if (alive) W[c.O.p + r] = acc;
             }
             wv::wave_fence();
             COOP_T(c, CT_PRE);
@@ -787,7 +1016,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             const bool failed = alive && !conv;
             if (wv::ballot(failed) != 0ull) {            // the policy of step! (src/ACME.jl:688-694)
                 bool nf = false;
-                for (int r = lig; r < s.nn; r += GROUP) nf = nf || !(W[H.w_zz + r] * 0.0 == 0.0);
+                for (int r = lig; r < s.nn; r += GROUP) nf = nf || !(W[c.O.zz + r] * 0.0 == 0.0);
                 const bool zfinite = !coop_any(c, nf);
                 if (failed && lig == 0) {
                     if (zfinite) {
@@ -800,7 +1029,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
                 dead = dead || (failed && !zfinite);
             }
             for (int r = lig; r < s.nn; r += GROUP)
-                if (alive) W[H.w_z + s.zoff + r] = W[H.w_zz + r];
+                if (alive) W[c.O.z + s.zoff + r] = W[c.O.zz + r];
             wv::wave_fence();
         }
         it_total += its_sample;
@@ -809,20 +1038,20 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         COOP_T(c, CT_REST);
         // y = y0 + dy x + ey u + fy z (old x, :699-706);  x = x0 + a x + b u + c z (:708-714)
         for (int r = lig; r < H.ny; r += GROUP) {
-            double acc = coop_dot(c.M + H.o_dy + r, H.ny, W + H.w_x, H.nx, c.M[H.o_y0 + r]);
+            double acc = coop_dot(c.M + H.o_dy + r, H.ny, W + c.O.x, H.nx, c.M[H.o_y0 + r]);
             acc = coop_dot(c.M + H.o_ey + r, H.ny, un, H.nu, acc);
-            acc = coop_dot(c.M + H.o_fy + r, H.ny, W + H.w_z, H.nnt, acc);
+            acc = coop_dot(c.M + H.o_fy + r, H.ny, W + c.O.z, H.nnt, acc);
             yn[r] = live ? acc : (double)NAN;
         }
         for (int r = lig; r < H.nx; r += GROUP) {
-            double acc = coop_dot(c.M + H.o_a + r, H.nx, W + H.w_x, H.nx, c.M[H.o_x0 + r]);
+            double acc = coop_dot(c.M + H.o_a + r, H.nx, W + c.O.x, H.nx, c.M[H.o_x0 + r]);
             acc = coop_dot(c.M + H.o_b + r, H.nx, un, H.nu, acc);
-            acc = coop_dot(c.M + H.o_c + r, H.nx, W + H.w_z, H.nnt, acc);
-            if (live) W[H.w_xn + r] = acc;
+            acc = coop_dot(c.M + H.o_c + r, H.nx, W + c.O.z, H.nnt, acc);
+            if (live) W[c.O.xn + r] = acc;
         }
         wv::wave_fence();
         for (int r = lig; r < H.nx; r += GROUP)
-            if (live) W[H.w_x + r] = W[H.w_xn + r];
+            if (live) W[c.O.x + r] = W[c.O.xn + r];
         wv::wave_fence();
         COOP_T(c, CT_XY);
     }
@@ -830,10 +1059,10 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     if (lig == 0 && A.T >= CT_N && H.ny > 0)
         for (int k = 0; k < CT_N; ++k) A.y[(i * A.T + k) * H.ny] = (double)tmr.t[k];
 #endif
-    for (int k = lig; k < H.nx; k += GROUP) st[k] = W[H.w_x + k];
+    for (int k = lig; k < H.nx; k += GROUP) st[k] = W[c.O.x + k];
     if (has_sub) {
-        for (int j = lig; j < s.np; j += GROUP) st[H.nx + s.poff + j] = W[s.w_lp + j];
-        for (int r = lig; r < s.nn; r += GROUP) st[H.nx + H.npt + s.zoff + r] = W[s.w_lz + r];
+        for (int j = lig; j < s.np; j += GROUP) st[H.nx + s.poff + j] = W[c.O.lp + j];
+        for (int r = lig; r < s.nn; r += GROUP) st[H.nx + H.npt + s.zoff + r] = W[c.O.lz + r];
         if (caching)
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) cache_g[k] = Cp[k];
     }

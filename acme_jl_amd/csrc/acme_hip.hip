@@ -81,7 +81,12 @@ __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
 
 // the mid-size kernel (acme_coop.h): one wave per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
 // (NC: the factor matrix's columns in registers -- 17 ... 32 unknowns -- or 0: factors in LDS, any size)
-template <bool IMGL, int NC> __global__ __launch_bounds__(64) void acme_coop_kernel(GArgs A) {
+// The any-size instantiation is held to 256 registers: left to itself it took 301 (the accumulation registers as spill
+// space) and then computed zeros whenever a wave carried fewer than four instances -- on the GPU only, at every size
+// (measured; the 256-register build is right at 1, 2 and 4 instances per wave, as are the register instantiations, which
+// tests/test_gpu_parity.py::test_mid_size_kernel checks at every group count).
+template <bool IMGL, int NC> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 0 ? 2 : 1)))
+void acme_coop_kernel(GArgs A) {
     extern __shared__ double acme_lds[];
     coop_main<IMGL, NC>(A, acme_lds, (int)blockIdx.x, (int)threadIdx.x);
 }

@@ -17,6 +17,10 @@ ACME_DEV void block_sync() { __syncthreads(); }
 // order; this only stops the compiler from reordering across it)
 ACME_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                              __builtin_amdgcn_wave_barrier(); }
+// the same ordering WITHOUT the s_waitcnt the release fence brings along: the DS pipeline serves a wave's operations in
+// program order, so a read issued right behind a write of another lane of the SAME wave sees it -- where the hand-off's
+// latency is the cost (a lone wave's pivot-row / x_j broadcasts through LDS), this saves one LDS round trip per hand-off
+ACME_DEV void lds_order() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
 // DPP moves with an undefined `old` operand: every lane of a row has a valid source for
 // row_newbcast / row_ror, so no destination pre-initialisation (no extra v_mov) is needed.

@@ -163,6 +163,7 @@ namespace wv {
 ACME_DEV int tid() { return emu::g_blk->fibers[emu::g_blk->cur].tid; }
 ACME_DEV int bid() { return emu::g_blk->bid; }
 ACME_DEV void block_sync() { emu::block_sync(); }
+ACME_DEV void lds_order() { emu::wave_sync(); }
 ACME_DEV void wave_fence() { emu::wave_sync(); }  // lanes run one after another here: LDS hand-offs need a rendezvous
 template <int K> ACME_DEV double bcast16(double v) {
     int lane = tid() & 63;

@@ -838,7 +838,9 @@ def test_host_arrays_may_be_freed_after_any_call(hip_lib):
 def test_mid_size_kernel(hip_lib, monkeypatch):
     """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 20 unknowns (what the reference's LU "for sizes up to about
     60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full waves and a ragged
-    last one): the oracle's outputs (RTOL_SAME) and iteration totals, and the lane-per-instance kernel's."""
+    last one): the oracle's outputs (RTOL_SAME) and iteration totals, and the lane-per-instance kernel's.  17 ... 32
+    unknowns run the instantiation with the running factorisation in registers; the any-size one (everything in LDS,
+    ACME_COOP_REG=0) gives the same bits and the same iteration counts, and so does either with 1, 2 or 4 instances per wave."""
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
@@ -853,6 +855,19 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
             err = assert_close(y, yref, rtol=RTOL_SAME)
             assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
+            # every instantiation at every group count (instances per wave: what the LDS of a compute unit holds most of
+            # by default, ACME_COOP_GPW otherwise -- a request that does not fit is ignored): the same bits
+            for reg in ("1", "0"):
+                for gpw in ("1", "2", "4"):
+                    monkeypatch.setenv("ACME_COOP_REG", reg)
+                    monkeypatch.setenv("ACME_COOP_GPW", gpw)
+                    rl = ModelRunner(m, N, lib=hip_lib)
+                    assert rl.kernel_family() == "coop"
+                    yl = np.concatenate([rl.run(u[:, :, :50]), rl.run(u[:, :, 50:])], axis=2)
+                    assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, reg, gpw)
+                    assert np.array_equal(y, yl), (name, solver, "registers" if reg == "1" else "LDS", gpw)
+            monkeypatch.delenv("ACME_COOP_REG")
+            monkeypatch.delenv("ACME_COOP_GPW")
             monkeypatch.setenv("ACME_COOP", "0")
             r0 = ModelRunner(m, N, lib=hip_lib)
             assert r0.kernel_family() == "generic"
