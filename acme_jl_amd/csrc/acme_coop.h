@@ -21,7 +21,7 @@
 // partially pivoted LU are real (the rows sit in LDS, not in lanes); the sequence of interchanges is kept as the composed
 // gather src[] (x_permuted[i] = x[src[i]]), which is what solve! applies first (src/solvers.jl:103-109).
 //
-// A wave never talks to another wave: blocks may be one wave (the GPU launch) or four (the CPU emulator's block).
+// A wave never talks to another wave once the block's shared tables are staged (one barrier).
 #pragma once
 #include "acme_generic.h"
 
@@ -33,7 +33,7 @@ constexpr int COOP_SLOTS = COOP_MAX_N / GROUP;
 #ifdef ACME_DEV
 // -DACME_COOP_TIMING (tools/coop_timing_probe.py): shader-clock cycles per code region, per wave, written over y's first samples
 #ifdef ACME_COOP_TIMING
-enum { CT_SETP, CT_EXTRAP, CT_EVAL, CT_LU, CT_SOLVE, CT_ACCEPT, CT_LOOKUP, CT_XY, CT_PRE, CT_REST, CT_N };
+enum { CT_SETP, CT_EXTRAP, CT_EVAL, CT_LU, CT_SOLVE, CT_ACCEPT, CT_LOOKUP, CT_XY, CT_PRE, CT_REST, CT_LU_SEARCH, CT_LU_HAND, CT_N };
 struct CoopTimer { long long t[CT_N]; long long mark; };
 #define COOP_T(c, b) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)__builtin_readcyclecounter(); \
                           (c).tm->t[b] += t_ - (c).tm->mark; (c).tm->mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -66,7 +66,7 @@ ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
     int w = 0;
     o.ld = nc + 2;                                   // (2 mod 4 doubles: the 16 rows of a DPP row in 16 bank groups)
     o.llu = w; w += nn * o.ld;                       // 16-byte aligned rows: offset and pitch even
-    o.prow = w; w += nc;
+    o.prow = w; w += nc + 2;                         // (the pivot row and, behind it, the position it came from)
     o.xb = w; w += nc;
     o.ljp = w; w += nn * np;
     o.lsrc = w; w += nn;
@@ -487,22 +487,33 @@ template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a
                     bp = pos[sl];
                 }
             });
-            const double m = wv::allmax16(best);
+            const double m = wv::allmax16_nn(best);
             // |pivot| is known here, its sign only after the row has come round: the division (a dozen dependent
-            // operations) runs beside the second reduction and the LDS round trip instead of behind them
+            // operations) runs beside the LDS round trip instead of behind it
             const double inv_abs = 1.0 / m;
-            const double kpd = wv::allmin16((best == m && m > 0.0) ? (double)bp : 1e9);
-            const int kp = kpd < (double)n ? (int)kpd : k;
+            // Whose is it?  Nearly always ONE lane of the instance holds the maximum: then that lane knows it is the
+            // holder, and the position kp it takes the row from travels with the row.  Only equal maxima in several lanes
+            // (or none: a zero / NaN column) need the second reduction, over the positions.
+            const bool top = best == m && m > 0.0;
+            const unsigned mine = (unsigned)(wv::ballot(top) >> (c.grp * GROUP)) & 0xFFFFu;
+            const bool fast = wv::ballot(mine == 0u || (mine & (mine - 1u)) != 0u) == 0ull;
+            int kp = 0;
+            if (!fast) {
+                const double kpd = wv::allmin16(top ? (double)bp : 1e9);
+                kp = kpd < (double)n ? (int)kpd : k;
+            }
+            COOP_T(c, CT_LU_SEARCH);
+            bool holds[NS];
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                const bool holds = real[sl] && pos[sl] == kp;
-                if (holds)
+                holds[sl] = real[sl] && (fast ? (top && pos[sl] == bp) : pos[sl] == kp);
+                if (holds[sl]) {
                     sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
                         constexpr int g = decltype(gc)::value;
                         wv::st2(P + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
                     });
-                // (the interchange: positions k and kp trade places)
-                pos[sl] = holds ? k : (pos[sl] == k ? kp : pos[sl]);
+                    if (fast) reinterpret_cast<int *>(P + NC)[0] = pos[sl];
+                }
             });
             wv::lds_order();
             double b[NC];
@@ -512,9 +523,19 @@ template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a
                 b[2 * g] = v.lo;
                 b[2 * g + 1] = v.hi;
             });
+            if (fast) kp = reinterpret_cast<const int *>(P + NC)[0];
+            // (the interchange: positions k and kp trade places)
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                pos[sl] = holds[sl] ? k : (pos[sl] == k ? kp : pos[sl]);
+            });
             const double piv = b[k];
             ok = ok && piv != 0.0;
             double inv = copysign(inv_abs, piv);
+#ifdef ACME_COOP_TIMING
+            inv = wv::keep(inv);
+            COOP_T(c, CT_LU_HAND);
+#endif
             if (wv::ballot(!(m > 0.0)) != 0ull) {          // no pivot candidate (a zero or NaN column): the reference's 1 / a_kk
                 const double direct = 1.0 / piv;
                 inv = m > 0.0 ? inv : direct;
@@ -926,32 +947,37 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
     return conv;
 }
 
-// run! for the instances of one wave (GArgs::mode == GEN_RUN).  lds: this wave's LDS (layout above); IMGL: the batch shares
-// one model image, staged in LDS -- a dependent load from L2 costs a lone wave ~1 us, and evaluate! alone chains five of them.
-template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_global, int lane) {
+// run! for the instances of one wave (GArgs::mode == GEN_RUN).  lds: the BLOCK's LDS -- GArgs::coop_wpb waves share one
+// copy of the row tables and (IMGL: the batch shares one model image) of the image, staged by all of them; behind that every
+// wave has its instances' workspaces.  A dependent load from L2 costs a lone wave ~1 us, and evaluate! alone chains five of
+// them: with four waves to a block the image of a 20-unknown model fits beside 16 instances' workspaces.  After the one
+// barrier behind the staging a wave never talks to another.
+template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_in_block, int wave_global, int lane) {
     const GenHeader &H = *A.H;
     const int lig = lane & (GROUP - 1), grp = lane >> 4;
-    const int gpw = A.coop_gpw;
+    const int gpw = A.coop_gpw, wpb = A.coop_wpb;
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));
-    // ---- the wave's shared part: model image (if shared) and row tables, loaded by all 64 lanes ----
+    // ---- the block's shared part: model image (if shared) and row tables, loaded by all its lanes ----
     double *img = lds;
     double *tk = lds + (IMGL ? ((H.image_total + 1) & ~1) : 0);
     const int blocks = (H.nnt + GROUP - 1) / GROUP;
     int *ti = reinterpret_cast<int *>(tk + blocks * 8 * GROUP);
+    const int t0 = wave_in_block * 64 + lane, tstep = wpb * 64;
     if constexpr (IMGL)
-        for (int k = lane; k < H.image_total; k += 64) img[k] = A.image[k];
-    for (int k = lane; k < blocks * 8 * GROUP; k += 64) {
+        for (int k = t0; k < H.image_total; k += tstep) img[k] = A.image[k];
+    for (int k = t0; k < blocks * 8 * GROUP; k += tstep) {
         const int blk = k / (8 * GROUP), rest = k % (8 * GROUP);
         tk[k] = A.rowc[(long long)blk * ROWC * GROUP + rest];       // constants 0 .. 7 of the block's 16 rows
     }
-    for (int k = lane; k < blocks * ROWI * GROUP; k += 64) ti[k] = A.rowi[k];
-    wv::wave_fence();
+    for (int k = t0; k < blocks * ROWI * GROUP; k += tstep) ti[k] = A.rowi[k];
+    if (wpb > 1) wv::block_sync();
+    else wv::wave_fence();
     const long long slot = (long long)wave_global * gpw + grp;
     const bool valid = grp < gpw && slot < A.n_inst;
     if (!valid) return;      // (a row of 16 lanes without an instance leaves: nothing below crosses the rows of a wave)
     const long long i = slot;
     const CoopOff O = coop_offsets(H, NC);
-    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)grp * coop_inst_doubles(H, NC);
+    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)(wave_in_block * gpw + grp) * coop_inst_doubles(H, NC);
     double *Cp = W + ((O.total + 1) & ~1);
     CoopCtx c{A, H, O, IMGL ? img : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid};
 #ifdef ACME_COOP_TIMING

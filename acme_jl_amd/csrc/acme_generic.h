@@ -72,6 +72,7 @@ struct GArgs {
     int solve_sub;
     int coop_imgl;           // acme_coop.h: the (shared) model image is staged in LDS
     int coop_gpw;            // acme_coop.h: instances per wave (4, 2 or 1: what the LDS of a compute unit holds most of)
+    int coop_wpb;            // acme_coop.h: waves per block (4, 2 or 1: they share one copy of the row tables / the image in LDS)
     int coop_nc;             // acme_coop.h: the kernel instantiated for this many columns of the factor matrix in registers
                              // (20, 24, 28, 32: 17 ... 32 unknowns rounded up to four); 0: the any-size kernel (factors in LDS)
 };

@@ -79,16 +79,17 @@ __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
     if (i < A.n_inst) gen_main(A, i);
 }
 
-// the mid-size kernel (acme_coop.h): one wave per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
+// the mid-size kernel (acme_coop.h): GArgs::coop_wpb waves per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
 // (NC: the factor matrix's columns in registers -- 17 ... 32 unknowns -- or 0: factors in LDS, any size)
 // The any-size instantiation is held to 256 registers: left to itself it took 301 (the accumulation registers as spill
 // space) and then computed zeros whenever a wave carried fewer than four instances -- on the GPU only, at every size
 // (measured; the 256-register build is right at 1, 2 and 4 instances per wave, as are the register instantiations, which
 // tests/test_gpu_parity.py::test_mid_size_kernel checks at every group count).
-template <bool IMGL, int NC> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 0 ? 2 : 1)))
+template <bool IMGL, int NC> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 0 ? 2 : 1)))
 void acme_coop_kernel(GArgs A) {
     extern __shared__ double acme_lds[];
-    coop_main<IMGL, NC>(A, acme_lds, (int)blockIdx.x, (int)threadIdx.x);
+    const int wave = (int)threadIdx.x >> 6;
+    coop_main<IMGL, NC>(A, acme_lds, wave, (int)blockIdx.x * A.coop_wpb + wave, (int)threadIdx.x & 63);
 }
 
 // placement of the waves by their measured cost (acme_balance.h): one thread per wave
@@ -167,8 +168,9 @@ template <bool IMGL, int NC> static inline int launch_coop_as(const GArgs &A, si
         if (rc != 0) return rc;
         allowed = lds_bytes;
     }
-    const dim3 grid((unsigned)((A.n_inst + A.coop_gpw - 1) / A.coop_gpw));
-    return ACME_LAUNCH((acme_coop_kernel<IMGL, NC>), grid, dim3(64), lds_bytes, st, A);
+    const long long waves = (A.n_inst + A.coop_gpw - 1) / A.coop_gpw;
+    const dim3 grid((unsigned)((waves + A.coop_wpb - 1) / A.coop_wpb));
+    return ACME_LAUNCH((acme_coop_kernel<IMGL, NC>), grid, dim3(64 * A.coop_wpb), lds_bytes, st, A);
 }
 template <bool IMGL> static inline int launch_coop_img(const GArgs &A, size_t lds_bytes, stream_t st) {
     switch (A.coop_nc) {

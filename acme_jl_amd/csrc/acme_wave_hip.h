@@ -286,6 +286,21 @@ ACME_DEV double allmax16(double v) {
     return v;
 }
 
+// ... of values that are not NaN: v_max_f64 as it is (fmax() quiets a possible signalling NaN first, one more
+// v_max_f64 per operand: two of three instructions of a reduction step)
+ACME_DEV double max_nn(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+ACME_DEV double allmax16_nn(double v) {
+    v = max_nn(v, ror16<8>(v));
+    v = max_nn(v, ror16<4>(v));
+    v = max_nn(v, ror16<2>(v));
+    v = max_nn(v, ror16<1>(v));
+    return v;
+}
+
 // min / sum over the 16 lanes of each row, result in every lane
 ACME_DEV double allmin16(double v) {
     v = fmin(v, ror16<8>(v));

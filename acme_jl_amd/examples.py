@@ -151,3 +151,22 @@ def rc_ladder(nstages=20, r=1e3, c=10e-9):
         pin = (rr, 2)
     circ.connect(pin, ("output", "+"))
     return circ
+
+
+def clipper_chain(stages):
+    """`stages` diode-clipper stages in a row (R - C||diode pair, loaded by the next stage's R) -- NOT one of the
+    reference's examples: a circuit whose nonlinearity does not decompose, so that undecomposed
+    (`decompose_nonlinearity=False`) it is ONE nonlinear sub-problem of 2*stages unknowns: the model for the padded kernel
+    shapes (up to 16 unknowns), the cooperative mid-size kernel (17 ... 64; bench.py's `clipper_chain_20`) and the
+    lane-per-instance generic kernel."""
+    spec = [("j_in", voltagesource(), {"-": "gnd"})]
+    prev = ("j_in", "+")
+    for k in range(stages):
+        r, c, d1, d2 = f"r{k}", f"c{k}", f"da{k}", f"db{k}"
+        spec += [(r, resistor(1e3 * (1 + 0.3 * k)), {1: prev}),
+                 (c, capacitor(47e-9 / (1 + 0.2 * k)), {1: (r, 2), 2: "gnd"}),
+                 (d1, diode(is_=1e-15 * (1 + k)), {"-": "gnd", "+": (r, 2)}),
+                 (d2, diode(is_=1.8e-15 * (1 + k)), {"-": (r, 2), "+": "gnd"})]
+        prev = (r, 2)
+    spec.append(("j_out", voltageprobe(), {"-": "gnd", "+": prev}))
+    return build(spec)

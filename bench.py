@@ -123,7 +123,7 @@ def kernel_name(runner, per_instance=False):
     """the dominant kernel as the rocprofv3 summaries name it (shape dimensions; condensed rows if any)"""
     nl, generic = runner.kernel_variant()
     if generic:
-        return "acme_generic_kernel (run-time dimensions %d,%d,%d,%d,%d,%d)" % runner.kernel_shape()
+        return ("acme_coop_kernel" if runner.kernel_family() == "coop" else "acme_generic_kernel") + " (run-time dimensions %d,%d,%d,%d,%d,%d)" % runner.kernel_shape()
     shape = runner.kernel_shape()
     # (the two smallest shapes run one LANE per instance unless ACME_LANE_KERNEL=0 or the batch has private images:
     # csrc/acme_api.inc use_lane_kernel)
@@ -342,10 +342,19 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3):
     from acme_jl_amd.runner import ModelRunner
     n = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(workload, 8192)
     fs = 176400 if workload == "birdie_grid" else FS
-    T = fs
+    T = fs // 10 if workload == "clipper_chain_20" else fs
     solver = HomotopySolver if workload == "birdie_grid" else CachingHomotopySolver
-    fixture, pots, amp = grid_inputs(workload, 0, 1, n, T)
-    model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
+    if workload == "clipper_chain_20":
+        # beyond BASELINE: ONE nonlinear sub-problem of 20 unknowns (the reference's LU is written for "sizes up to about
+        # 60 x 60", src/solvers.jl:53-54; nldecompose! leaves such sub-problems whenever a circuit does not decompose) --
+        # the cooperative mid-size kernel (csrc/acme_coop.h), a tenth of a second of audio per step
+        from fractions import Fraction
+        from acme_jl_amd import examples
+        model = DiscreteModel(examples.clipper_chain(10), Fraction(1, fs), solver, decompose_nonlinearity=False)
+        pots, amp = None, 10.0 ** np.linspace(-2, 0.7, n)
+    else:
+        fixture, pots, amp = grid_inputs(workload, 0, 1, n, T)
+        model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
     if workload == "superover_montecarlo":
         batch = montecarlo_models(0, n, init_on_device={"device": local_rank})
         batch.solver = solver
@@ -376,7 +385,7 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3):
             "lds_bank_conflict_frac": pmc_lds_bank_conflict_frac(prec),
             "fp64_executed_tflops": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12) if fx else None,
             "profiled_kernel_ms": (prec or {}).get("kernel_avg_ms_profiled")}
-    return {"workload": workload, "roofline": roof, "config": {"diodeclipper_sweep": 2, "superover_montecarlo": 4, "birdie_grid": 5}[workload],
+    return {"workload": workload, "roofline": roof, "config": {"diodeclipper_sweep": 2, "superover_montecarlo": 4, "birdie_grid": 5}.get(workload),
             "instances": n, "samples_per_step": T, "fs": fs, "solver": model.solver, "steps": steps, "warmup": warmup,
             "value": n * T * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": kms,
             "kernel": kname,
@@ -622,11 +631,12 @@ def main():
     if world == 1 and not args.no_host_path:
         host = host_buffer_leg(runner, u, n_per_gpu, T, model)
     # BASELINE configs 2, 4 and 5 next to the headline (config 3): one short steady-state measurement each, reported
-    # under config.other_workloads -- every BASELINE number in the driver's own record.  Never `value`.
+    # under config.other_workloads -- every BASELINE number in the driver's own record -- and, beyond BASELINE, one
+    # 20-unknown sub-problem on the mid-size kernel (config: null).  Never `value`.
     others = None
     if world == 1 and args.workload == "superover_grid" and not args.no_other_workloads:
         others = []
-        for wl in ("diodeclipper_sweep", "superover_montecarlo", "birdie_grid"):
+        for wl in ("diodeclipper_sweep", "superover_montecarlo", "birdie_grid", "clipper_chain_20"):
             try:
                 others.append(other_workload_leg(wl, local_rank, dev))
             except Exception as e:      # (the headline line must come out whatever happens here)

@@ -150,22 +150,9 @@ def two_stage_clipper(bias=0.0):
 
 
 def clipper_chain(stages):
-    """`stages` diode-clipper stages in a row (R - C||diode pair, loaded by the next stage's R):
-    undecomposed it is one nonlinear sub-problem with nn = 2*stages -- a model for the generic
-    (padded) kernel shapes up to nn = 16."""
-    from acme_jl_amd.circuit import capacitor, diode, resistor, voltageprobe, voltagesource
-    from acme_jl_amd.examples import build
-    spec = [("j_in", voltagesource(), {"-": "gnd"})]
-    prev = ("j_in", "+")
-    for k in range(stages):
-        r, c, d1, d2 = f"r{k}", f"c{k}", f"da{k}", f"db{k}"
-        spec += [(r, resistor(1e3 * (1 + 0.3 * k)), {1: prev}),
-                 (c, capacitor(47e-9 / (1 + 0.2 * k)), {1: (r, 2), 2: "gnd"}),
-                 (d1, diode(is_=1e-15 * (1 + k)), {"-": "gnd", "+": (r, 2)}),
-                 (d2, diode(is_=1.8e-15 * (1 + k)), {"-": (r, 2), "+": "gnd"})]
-        prev = (r, 2)
-    spec.append(("j_out", voltageprobe(), {"-": "gnd", "+": prev}))
-    return build(spec)
+    """acme_jl_amd.examples.clipper_chain (bench.py's mid-size workload is the same circuit)"""
+    from acme_jl_amd.examples import clipper_chain as make
+    return make(stages)
 
 
 def buffered_clipper_chain(stages, bias=0.0):

@@ -254,29 +254,30 @@ static inline int launch_generic(const GArgs &A, stream_t) {
     for (long long i = 0; i < A.n_inst; ++i) gen_main(A, i);
     return 0;
 }
-// the mid-size kernel (acme_coop.h): an emulated block is four of its one-wave blocks
-struct CoopLaunch { const GArgs *A; double *lds; size_t per_wave; int bid; };
+// the mid-size kernel (acme_coop.h): an emulated block (four waves) is one of its blocks of GArgs::coop_wpb waves -- the
+// waves beyond that leave at once
+struct CoopLaunch { const GArgs *A; double *lds; int bid; };
 static void coop_fiber_entry(void *p) {
     CoopLaunch *c = (CoopLaunch *)p;
-    const int tid = wv::tid(), wave = tid >> 6;
-    double *lds = c->lds + (size_t)wave * c->per_wave;
-    const int wg = c->bid * WAVES_PER_BLOCK + wave, lane = tid & 63;
+    const int tid = wv::tid(), wave = tid >> 6, wpb = c->A->coop_wpb;
+    if (wave >= wpb) return;
+    double *lds = c->lds;
+    const int wg = c->bid * wpb + wave, lane = tid & 63;
     const bool img = c->A->coop_imgl != 0;
     switch (c->A->coop_nc) {
-    case 20: img ? coop_main<true, 20>(*c->A, lds, wg, lane) : coop_main<false, 20>(*c->A, lds, wg, lane); break;
-    case 24: img ? coop_main<true, 24>(*c->A, lds, wg, lane) : coop_main<false, 24>(*c->A, lds, wg, lane); break;
-    case 28: img ? coop_main<true, 28>(*c->A, lds, wg, lane) : coop_main<false, 28>(*c->A, lds, wg, lane); break;
-    case 32: img ? coop_main<true, 32>(*c->A, lds, wg, lane) : coop_main<false, 32>(*c->A, lds, wg, lane); break;
-    default: img ? coop_main<true, 0>(*c->A, lds, wg, lane) : coop_main<false, 0>(*c->A, lds, wg, lane); break;
+    case 20: img ? coop_main<true, 20>(*c->A, lds, wave, wg, lane) : coop_main<false, 20>(*c->A, lds, wave, wg, lane); break;
+    case 24: img ? coop_main<true, 24>(*c->A, lds, wave, wg, lane) : coop_main<false, 24>(*c->A, lds, wave, wg, lane); break;
+    case 28: img ? coop_main<true, 28>(*c->A, lds, wave, wg, lane) : coop_main<false, 28>(*c->A, lds, wave, wg, lane); break;
+    case 32: img ? coop_main<true, 32>(*c->A, lds, wave, wg, lane) : coop_main<false, 32>(*c->A, lds, wave, wg, lane); break;
+    default: img ? coop_main<true, 0>(*c->A, lds, wave, wg, lane) : coop_main<false, 0>(*c->A, lds, wave, wg, lane); break;
     }
 }
 static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t) {
-    const size_t per_wave = lds_bytes / sizeof(double);
-    std::vector<double> lds(per_wave * WAVES_PER_BLOCK + 64);
+    std::vector<double> lds(lds_bytes / sizeof(double) + 64);
     const long long waves = (A.n_inst + A.coop_gpw - 1) / A.coop_gpw;
-    for (long long b = 0; b * WAVES_PER_BLOCK < waves; ++b) {
+    for (long long b = 0; b * A.coop_wpb < waves; ++b) {
         for (auto &v : lds) v = std::nan("");
-        CoopLaunch c{&A, lds.data(), per_wave, (int)b};
+        CoopLaunch c{&A, lds.data(), (int)b};
         emu::run_block((int)b, &coop_fiber_entry, &c);
     }
     return 0;

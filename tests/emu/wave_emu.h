@@ -222,6 +222,7 @@ ACME_DEV double allmax16(double v) {
     v = fmax(v, ror16<1>(v));
     return v;
 }
+ACME_DEV double allmax16_nn(double v) { return allmax16(v); }
 ACME_DEV double allmin16(double v) {
     v = fmin(v, ror16<8>(v));
     v = fmin(v, ror16<4>(v));

@@ -901,6 +901,18 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
             monkeypatch.delenv("ACME_COOP", raising=False)
             assert np.array_equal(outs["coop"], outs["coop, private images"]), name
             assert np.array_equal(outs["coop"], outs["coop, factors in LDS"]), name
+            # the launch shape (waves per block sharing the staged tables / image, instances per wave, image in LDS or
+            # not: csrc/acme_api.inc coop_shape) does not show in the bits
+            if solver is HS:
+                for reg, wpb, gpw, imgl in (("1", "4", "4", "1"), ("1", "3", "2", "0"), ("0", "2", "1", "1"), ("0", "1", "4", "0")):
+                    for k, v in (("ACME_COOP_REG", reg), ("ACME_COOP_WPB", wpb), ("ACME_COOP_GPW", gpw), ("ACME_COOP_IMGL", imgl)):
+                        monkeypatch.setenv(k, v)
+                    r = ModelRunner(m, u.shape[0], lib=emu_lib)
+                    y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+                    assert np.array_equal(y, outs["coop"]), (name, reg, wpb, gpw, imgl)
+                    assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, reg, wpb, gpw, imgl)
+                for k in ("ACME_COOP_REG", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL"):
+                    monkeypatch.delenv(k)
             assert np.abs(outs["coop"] - outs["lane per instance"]).max() <= 1e-13 * max(1.0, np.abs(yref).max()), name
 
 

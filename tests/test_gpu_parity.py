@@ -840,7 +840,7 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
     60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full waves and a ragged
     last one): the oracle's outputs (RTOL_SAME) and iteration totals, and the lane-per-instance kernel's.  17 ... 32
     unknowns run the instantiation with the running factorisation in registers; the any-size one (everything in LDS,
-    ACME_COOP_REG=0) gives the same bits and the same iteration counts, and so does either with 1, 2 or 4 instances per wave."""
+    ACME_COOP_REG=0) gives the same bits and the same iteration counts, and so does either in any launch shape."""
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
@@ -855,19 +855,21 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
             err = assert_close(y, yref, rtol=RTOL_SAME)
             assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
-            # every instantiation at every group count (instances per wave: what the LDS of a compute unit holds most of
-            # by default, ACME_COOP_GPW otherwise -- a request that does not fit is ignored): the same bits
+            # every instantiation in every launch shape (waves per block sharing the staged tables / image, instances per
+            # wave, image in LDS or in L2 -- by default whatever keeps most instances resident, csrc/acme_api.inc
+            # coop_shape; a pinned shape that does not fit is ignored): the same bits
+            pins = ("ACME_COOP_REG", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL")
             for reg in ("1", "0"):
-                for gpw in ("1", "2", "4"):
-                    monkeypatch.setenv("ACME_COOP_REG", reg)
-                    monkeypatch.setenv("ACME_COOP_GPW", gpw)
+                for shape in ("110", "120", "140", "241", "321", "441", "420", "411"):
+                    for k, v in zip(pins, (reg,) + tuple(shape)):
+                        monkeypatch.setenv(k, v)
                     rl = ModelRunner(m, N, lib=hip_lib)
                     assert rl.kernel_family() == "coop"
                     yl = np.concatenate([rl.run(u[:, :, :50]), rl.run(u[:, :, 50:])], axis=2)
-                    assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, reg, gpw)
-                    assert np.array_equal(y, yl), (name, solver, "registers" if reg == "1" else "LDS", gpw)
-            monkeypatch.delenv("ACME_COOP_REG")
-            monkeypatch.delenv("ACME_COOP_GPW")
+                    assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, reg, shape)
+                    assert np.array_equal(y, yl), (name, solver, "registers" if reg == "1" else "LDS", shape)
+            for k in pins:
+                monkeypatch.delenv(k)
             monkeypatch.setenv("ACME_COOP", "0")
             r0 = ModelRunner(m, N, lib=hip_lib)
             assert r0.kernel_family() == "generic"

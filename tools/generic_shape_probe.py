@@ -33,7 +33,8 @@ cases = [
     ("clipper chain, 12 stages (nn 24) [generic]", DiscreteModel(circuits.clipper_chain(12), t, CachingHomotopySolver, decompose_nonlinearity=False)),
     ("clipper chain, 16 stages (nn 32) [generic]", DiscreteModel(circuits.clipper_chain(16), t, CachingHomotopySolver, decompose_nonlinearity=False)),
 ]
-if len(sys.argv) > 3:      # a subset by substring
+if len(sys.argv) > 3:      # a subset by substring (underscores stand for blanks)
+    sys.argv[3] = sys.argv[3].replace("_", " ")
     cases = [c for c in cases if sys.argv[3] in c[0]]
 dev = torch.device("cuda", 0)
 sig = torch.sin(2 * np.pi * 1000 / 44100 * torch.arange(T, dtype=torch.float64, device=dev))
