@@ -153,12 +153,14 @@ def rc_ladder(nstages=20, r=1e3, c=10e-9):
     return circ
 
 
-def clipper_chain(stages):
+def clipper_chain(stages, tail=False, symmetric=False):
     """`stages` diode-clipper stages in a row (R - C||diode pair, loaded by the next stage's R) -- NOT one of the
     reference's examples: a circuit whose nonlinearity does not decompose, so that undecomposed
     (`decompose_nonlinearity=False`) it is ONE nonlinear sub-problem of 2*stages unknowns: the model for the padded kernel
     shapes (up to 16 unknowns), the cooperative mid-size kernel (17 ... 64; bench.py's `clipper_chain_20`) and the
-    lane-per-instance generic kernel."""
+    lane-per-instance generic kernel.  tail: one more series resistor with a single diode to ground behind the last
+    stage (an odd number of unknowns); symmetric: both diodes of a stage alike (Jacobian entries of equal magnitude: the
+    pivot search meets ties)."""
     spec = [("j_in", voltagesource(), {"-": "gnd"})]
     prev = ("j_in", "+")
     for k in range(stages):
@@ -166,7 +168,10 @@ def clipper_chain(stages):
         spec += [(r, resistor(1e3 * (1 + 0.3 * k)), {1: prev}),
                  (c, capacitor(47e-9 / (1 + 0.2 * k)), {1: (r, 2), 2: "gnd"}),
                  (d1, diode(is_=1e-15 * (1 + k)), {"-": "gnd", "+": (r, 2)}),
-                 (d2, diode(is_=1.8e-15 * (1 + k)), {"-": (r, 2), "+": "gnd"})]
+                 (d2, diode(is_=(1.0e-15 if symmetric else 1.8e-15) * (1 + k)), {"-": (r, 2), "+": "gnd"})]
         prev = (r, 2)
+    if tail:
+        spec += [("rt", resistor(4.7e3), {1: prev}),
+                 ("dt", diode(is_=3e-15), {"-": "gnd", "+": ("rt", 2)})]
     spec.append(("j_out", voltageprobe(), {"-": "gnd", "+": prev}))
     return build(spec)

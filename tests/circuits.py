@@ -149,10 +149,10 @@ def two_stage_clipper(bias=0.0):
     ])
 
 
-def clipper_chain(stages):
+def clipper_chain(stages, tail=False, symmetric=False):
     """acme_jl_amd.examples.clipper_chain (bench.py's mid-size workload is the same circuit)"""
     from acme_jl_amd.examples import clipper_chain as make
-    return make(stages)
+    return make(stages, tail, symmetric)
 
 
 def buffered_clipper_chain(stages, bias=0.0):

@@ -183,14 +183,24 @@ def beyond_the_tuned_shapes():
             ("40-stage RC ladder", DiscreteModel(examples.rc_ladder(40), t, HS), u)]
 
 
-def mid_size_models():
+def mid_size_models(more=False):
     """(name, model, u[N, nu, T]) in the cooperative mid-size kernel's range (csrc/acme_coop.h): ONE sub-problem of 24 / 32
-    unknowns -- two rows per lane, the second group of 16 rows full or half full."""
+    unknowns -- two rows per lane, the second group of 16 rows full or half full -- and of 18 / 27: sizes that are not a
+    multiple of four (the register instantiations carry whole groups of four columns, the last one padded), one of
+    them odd.  more: also 34 unknowns (beyond the register instantiations: three rows per lane, everything in LDS)."""
     from fractions import Fraction
     import circuits
     from acme_jl_amd.model import DiscreteModel
     t = Fraction(1, FS)
     amp = np.array([0.05, 0.4, 1.0, 2.5, 4.0])          # (5 instances: a wave of four and a wave of one)
     u = amp[:, None, None] * sine(120)[None, None, :]
-    return [("24 unknowns", DiscreteModel(circuits.clipper_chain(12), t, HS, decompose_nonlinearity=False), u),
-            ("32 unknowns", DiscreteModel(circuits.clipper_chain(16), t, HS, decompose_nonlinearity=False), u)]
+    models = [("24 unknowns", DiscreteModel(circuits.clipper_chain(12), t, HS, decompose_nonlinearity=False), u),
+              ("32 unknowns", DiscreteModel(circuits.clipper_chain(16), t, HS, decompose_nonlinearity=False), u),
+              ("18 unknowns", DiscreteModel(circuits.clipper_chain(9), t, HS, decompose_nonlinearity=False), u),
+              ("27 unknowns", DiscreteModel(circuits.clipper_chain(13, tail=True), t, HS, decompose_nonlinearity=False), u),
+              # (both diodes of a stage alike: columns with entries of equal magnitude -- which row the pivot search takes
+              # on a tie must be the reference's, the first in the order the interchanges so far have left)
+              ("22 unknowns, ties", DiscreteModel(circuits.clipper_chain(11, symmetric=True), t, HS, decompose_nonlinearity=False), u)]
+    if more:
+        models.append(("34 unknowns", DiscreteModel(circuits.clipper_chain(17), t, HS, decompose_nonlinearity=False), u))
+    return models

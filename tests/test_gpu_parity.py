@@ -836,7 +836,7 @@ def test_host_arrays_may_be_freed_after_any_call(hip_lib):
 
 
 def test_mid_size_kernel(hip_lib, monkeypatch):
-    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 20 unknowns (what the reference's LU "for sizes up to about
+    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 18 / 27 / 34 / 20 unknowns (what the reference's LU "for sizes up to about
     60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full waves and a ragged
     last one): the oracle's outputs (RTOL_SAME) and iteration totals, and the lane-per-instance kernel's.  17 ... 32
     unknowns run the instantiation with the running factorisation in registers; the any-size one (everything in LDS,
@@ -844,7 +844,7 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
-    for name, m, u5 in mid_size_models() + beyond_the_tuned_shapes()[:1]:
+    for name, m, u5 in mid_size_models(more=True) + beyond_the_tuned_shapes()[:1]:
         N, T = 70, u5.shape[2]
         u = np.logspace(-1.5, 0.6, N)[:, None, None] * u5[2:3] / np.abs(u5[2]).max()
         for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
