@@ -123,15 +123,50 @@ ACME_DEV bool coop_any(const CoopCtx &c, bool x) { return ((wv::ballot(x) >> (c.
 constexpr int COOP_B = 8;
 // acc + sum_{j < n} a[j * sa] * b[j], accumulated in the order j = 0, 1, ... (fma chain, as the generic kernel's loops)
 ACME_DEV double coop_dot(const double *a, int sa, const double *b, int n, double acc) {
-    for (int j = 0; j < n; j += COOP_B) {
+    int j = 0;
+    for (; j + COOP_B <= n; j += COOP_B) {                 // whole batches: no index clamp, no predicate
         double av[COOP_B], bv[COOP_B];
         for (int u = 0; u < COOP_B; ++u) {
-            const int jj = j + u < n ? j + u : n - 1;      // (the tail re-reads the last operand: never out of range)
+            av[u] = a[(j + u) * sa];
+            bv[u] = b[j + u];
+        }
+        for (int u = 0; u < COOP_B; ++u) acc = fma(av[u], bv[u], acc);
+    }
+    if (j < n) {                                           // the rest
+        double av[COOP_B], bv[COOP_B];
+        for (int u = 0; u < COOP_B; ++u) {
+            const int jj = j + u < n ? j + u : n - 1;      // (re-reads the last operand: never out of range)
             av[u] = a[jj * sa];
             bv[u] = b[jj];
         }
         for (int u = 0; u < COOP_B; ++u)
             if (j + u < n) acc = fma(av[u], bv[u], acc);
+    }
+    return acc;
+}
+
+// acc + sum_{j < n} a[j * sa] * (b[j] - b0[j]), likewise
+ACME_DEV double coop_dot_diff(const double *a, int sa, const double *b, const double *b0, int n, double acc) {
+    int j = 0;
+    for (; j + COOP_B <= n; j += COOP_B) {
+        double av[COOP_B], bv[COOP_B], lv[COOP_B];
+        for (int u = 0; u < COOP_B; ++u) {
+            av[u] = a[(j + u) * sa];
+            bv[u] = b[j + u];
+            lv[u] = b0[j + u];
+        }
+        for (int u = 0; u < COOP_B; ++u) acc = fma(av[u], bv[u] - lv[u], acc);
+    }
+    if (j < n) {
+        double av[COOP_B], bv[COOP_B], lv[COOP_B];
+        for (int u = 0; u < COOP_B; ++u) {
+            const int jj = j + u < n ? j + u : n - 1;
+            av[u] = a[jj * sa];
+            bv[u] = b[jj];
+            lv[u] = b0[jj];
+        }
+        for (int u = 0; u < COOP_B; ++u)
+            if (j + u < n) acc = fma(av[u], bv[u] - lv[u], acc);
     }
     return acc;
 }
@@ -488,9 +523,6 @@ template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a
                 }
             });
             const double m = wv::allmax16_nn(best);
-            // |pivot| is known here, its sign only after the row has come round: the division (a dozen dependent
-            // operations) runs beside the LDS round trip instead of behind it
-            const double inv_abs = 1.0 / m;
             // Whose is it?  Nearly always ONE lane of the instance holds the maximum: then that lane knows it is the
             // holder, and the position kp it takes the row from travels with the row.  Only equal maxima in several lanes
             // (or none: a zero / NaN column) need the second reduction, over the positions.
@@ -524,6 +556,11 @@ template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a
                 b[2 * g + 1] = v.hi;
             });
             if (fast) kp = reinterpret_cast<const int *>(P + NC)[0];
+            // |pivot| is the reduction's result, its sign comes with the row: the division (a dozen dependent operations)
+            // is issued BEHIND the reads and ahead of their first use -- it runs while the row is on its way
+            wv::sched_fence();
+            const double inv_abs = 1.0 / m;
+            wv::sched_fence();
             // (the interchange: positions k and kp trade places)
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
@@ -727,21 +764,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
     coop_set_p(c, s, w_p);
     COOP_T(c, CT_SETP);
     // z <- last_z - last_J \ (last_Jp (p - last_p))
-    for (int r = c.lig; r < nn; r += GROUP) {
-        double acc = 0.0;
-        for (int j = 0; j < np; j += COOP_B) {
-            double jv[COOP_B], pv[COOP_B], lv[COOP_B];
-            for (int u = 0; u < COOP_B; ++u) {
-                const int jj = j + u < np ? j + u : np - 1;
-                jv[u] = W[c.O.ljp + jj * nn + r];
-                pv[u] = W[w_p + jj];
-                lv[u] = W[c.O.lp + jj];
-            }
-            for (int u = 0; u < COOP_B; ++u)
-                if (j + u < np) acc = fma(jv[u], pv[u] - lv[u], acc);
-        }
-        W[c.O.tmp + r] = acc;
-    }
+    for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
     wv::wave_fence();
     coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
     for (int r = c.lig; r < nn; r += GROUP)
@@ -1063,17 +1086,19 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         const bool live = !dead;
         COOP_T(c, CT_REST);
         // y = y0 + dy x + ey u + fy z (old x, :699-706);  x = x0 + a x + b u + c z (:708-714)
-        for (int r = lig; r < H.ny; r += GROUP) {
-            double acc = coop_dot(c.M + H.o_dy + r, H.ny, W + c.O.x, H.nx, c.M[H.o_y0 + r]);
-            acc = coop_dot(c.M + H.o_ey + r, H.ny, un, H.nu, acc);
-            acc = coop_dot(c.M + H.o_fy + r, H.ny, W + c.O.z, H.nnt, acc);
-            yn[r] = live ? acc : (double)NAN;
-        }
-        for (int r = lig; r < H.nx; r += GROUP) {
-            double acc = coop_dot(c.M + H.o_a + r, H.nx, W + c.O.x, H.nx, c.M[H.o_x0 + r]);
-            acc = coop_dot(c.M + H.o_b + r, H.nx, un, H.nu, acc);
-            acc = coop_dot(c.M + H.o_c + r, H.nx, W + c.O.z, H.nnt, acc);
-            if (live) W[c.O.xn + r] = acc;
+        // (ONE pass over the nx + ny rows -- a lane takes a state row or an output row, the vectors are the same: the two
+        // loops cost two sets of latencies for mostly idle lanes)
+        for (int rho = lig; rho < H.nx + H.ny; rho += GROUP) {
+            const bool isx = rho < H.nx;
+            const int r = isx ? rho : rho - H.nx, ldm = isx ? H.nx : H.ny;
+            double acc = coop_dot(c.M + (isx ? H.o_a : H.o_dy) + r, ldm, W + c.O.x, H.nx, c.M[(isx ? H.o_x0 : H.o_y0) + r]);
+            acc = coop_dot(c.M + (isx ? H.o_b : H.o_ey) + r, ldm, un, H.nu, acc);
+            acc = coop_dot(c.M + (isx ? H.o_c : H.o_fy) + r, ldm, W + c.O.z, H.nnt, acc);
+            if (isx) {
+                if (live) W[c.O.xn + r] = acc;
+            } else {
+                yn[r] = live ? acc : (double)NAN;
+            }
         }
         wv::wave_fence();
         for (int r = lig; r < H.nx; r += GROUP)
