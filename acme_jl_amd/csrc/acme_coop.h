@@ -496,55 +496,37 @@ ACME_DEV void coop_calc_jp_rows(const CoopCtx &c, const GenSub &s, const double 
 
 // setlhs! on the rows in registers; pos: the rows' positions in the factored matrix.  Returns false for the instances that
 // met an exactly zero pivot.
-template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][NC], int (&pos)[COOP_REG_SLOTS]) {
+// last (in / out): the positions the rows ended at in this instance's PREVIOUS factorisation (-1: none).  One Jacobian is
+// much like the one before it, so the row that was the pivot of step k last time is nearly always the pivot again: it
+// puts itself on the way to the others BEFORE the search has said so, and the search (two dependent reductions' worth of
+// latency) then runs beside the LDS round trip instead of ahead of it.  The search still decides: unless it finds exactly
+// that row -- the only lane of its instance holding the maximum, its smaller position on a tie inside the lane -- in all
+// four instances of the wave, the step is done again the plain way (search, then hand-off).  Same pivots, same arithmetic.
+template <int NC>
+ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][NC], int (&pos)[COOP_REG_SLOTS], int (&last)[COOP_REG_SLOTS]) {
     static_assert(NC % 4 == 0 && NC <= GROUP * COOP_REG_SLOTS, "columns in pairs, two rows per lane");
     constexpr int NS = COOP_REG_SLOTS;
-    double *P = c.W + c.O.prow;               // the step's pivot row (16-byte aligned)
-    bool real[NS];
-    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+    double *P = c.W + c.O.prow;               // the step's pivot row (16-byte aligned), behind it the position it came from
+    int *Pk = reinterpret_cast<int *>(P + NC);
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {          // (a slot without a row: position -1, never a candidate, never updated)
         constexpr int sl = decltype(sc)::value;
-        pos[sl] = c.lig + GROUP * sl;
-        real[sl] = pos[sl] < n;
+        pos[sl] = c.lig + GROUP * sl < n ? c.lig + GROUP * sl : -1;
     });
     bool ok = true;
     sfor<0, NC>([&](auto kc) ACME_LAMBDA {
         constexpr int k = decltype(kc)::value;
         if (k < n) {
-            // the pivot: the largest |a_ik| among the rows at positions >= k, the smallest position among equals
-            double best = -1.0;
-            int bp = 1 << 30;
-            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                const double v = fabs(a[sl][k]);
-                const bool cand = real[sl] && pos[sl] >= k;
-                if (cand && (v > best || (v == best && pos[sl] < bp))) {
-                    best = v;
-                    bp = pos[sl];
-                }
-            });
-            const double m = wv::allmax16_nn(best);
-            // Whose is it?  Nearly always ONE lane of the instance holds the maximum: then that lane knows it is the
-            // holder, and the position kp it takes the row from travels with the row.  Only equal maxima in several lanes
-            // (or none: a zero / NaN column) need the second reduction, over the positions.
-            const bool top = best == m && m > 0.0;
-            const unsigned mine = (unsigned)(wv::ballot(top) >> (c.grp * GROUP)) & 0xFFFFu;
-            const bool fast = wv::ballot(mine == 0u || (mine & (mine - 1u)) != 0u) == 0ull;
-            int kp = 0;
-            if (!fast) {
-                const double kpd = wv::allmin16(top ? (double)bp : 1e9);
-                kp = kpd < (double)n ? (int)kpd : k;
-            }
-            COOP_T(c, CT_LU_SEARCH);
+            // ---- last time's pivot row of this step sets out ----
             bool holds[NS];
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                holds[sl] = real[sl] && (fast ? (top && pos[sl] == bp) : pos[sl] == kp);
+                holds[sl] = last[sl] == k && pos[sl] >= k;
                 if (holds[sl]) {
                     sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
                         constexpr int g = decltype(gc)::value;
                         wv::st2(P + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
                     });
-                    if (fast) reinterpret_cast<int *>(P + NC)[0] = pos[sl];
+                    Pk[0] = pos[sl];
                 }
             });
             wv::lds_order();
@@ -555,31 +537,61 @@ template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a
                 b[2 * g] = v.lo;
                 b[2 * g + 1] = v.hi;
             });
-            if (fast) kp = reinterpret_cast<const int *>(P + NC)[0];
-            // |pivot| is the reduction's result, its sign comes with the row: the division (a dozen dependent operations)
-            // is issued BEHIND the reads and ahead of their first use -- it runs while the row is on its way
-            wv::sched_fence();
-            const double inv_abs = 1.0 / m;
-            wv::sched_fence();
-            // (the interchange: positions k and kp trade places)
+            int kp = Pk[0];
+            double inv = 1.0 / b[k];          // (beside the search, not behind its verdict: a dozen dependent operations)
+            // ---- the pivot: the largest |a_ik| among the rows at positions >= k, the smallest position among equals ----
+            double best = -1.0;
+            int bp = 1 << 30;
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                pos[sl] = holds[sl] ? k : (pos[sl] == k ? kp : pos[sl]);
+                const double v = fabs(a[sl][k]);
+                const bool cand = pos[sl] >= k;
+                if (cand && (v > best || (v == best && pos[sl] < bp))) {
+                    best = v;
+                    bp = pos[sl];
+                }
             });
+            const double m = wv::allmax16_nn(best);
+            const bool top = best == m && m > 0.0;
+            const bool sent = holds[0] || holds[1];
+            const int sent_pos = holds[0] ? pos[0] : pos[1];
+            const bool agree = m > 0.0 && (sent ? (top && bp == sent_pos) : !top);
+            COOP_T(c, CT_LU_SEARCH);
+            if (!ACME_USUAL(wv::ballot(!agree) == 0ull)) {
+                // the plain way: who holds it (the second reduction, over the positions), then the hand-off
+                const double kpd = wv::allmin16(top ? (double)bp : 1e9);
+                kp = kpd < (double)n ? (int)kpd : k;
+                sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                    constexpr int sl = decltype(sc)::value;
+                    holds[sl] = pos[sl] == kp;
+                    if (holds[sl])
+                        sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
+                            constexpr int g = decltype(gc)::value;
+                            wv::st2(P + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
+                        });
+                });
+                wv::lds_order();
+                sfor<k / 2, NC / 2>([&](auto gc) ACME_LAMBDA {
+                    constexpr int g = decltype(gc)::value;
+                    const wv::pair_t v = wv::ld2(P + 2 * g);
+                    b[2 * g] = v.lo;
+                    b[2 * g + 1] = v.hi;
+                });
+                wv::lds_order();          // (these reads before the next step's early write: program order on the GPU,
+                                          //  a rendezvous for the emulator's lanes, which run one after the other)
+                inv = 1.0 / b[k];
+            }
             const double piv = b[k];
             ok = ok && piv != 0.0;
-            double inv = copysign(inv_abs, piv);
 #ifdef ACME_COOP_TIMING
             inv = wv::keep(inv);
             COOP_T(c, CT_LU_HAND);
 #endif
-            if (wv::ballot(!(m > 0.0)) != 0ull) {          // no pivot candidate (a zero or NaN column): the reference's 1 / a_kk
-                const double direct = 1.0 / piv;
-                inv = m > 0.0 ? inv : direct;
-            }
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                if (real[sl] && pos[sl] > k) {
+                // (the interchange: positions k and kp trade places)
+                pos[sl] = holds[sl] ? k : (pos[sl] == k ? kp : pos[sl]);
+                if (pos[sl] > k) {
                     const double l = a[sl][k] * inv;
                     a[sl][k] = l;
                     sfor<k + 1, NC>([&](auto jc) ACME_LAMBDA {
@@ -587,10 +599,11 @@ template <int NC> ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a
                         a[sl][j] -= l * b[j];
                     });
                 }
-                if (real[sl] && pos[sl] == k) a[sl][k] = inv;          // the reciprocal on the diagonal (src/solvers.jl:86)
+                if (pos[sl] == k) a[sl][k] = inv;          // the reciprocal on the diagonal (src/solvers.jl:86)
             });
         }
     });
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA { last[decltype(sc)::value] = pos[decltype(sc)::value]; });
     return ok;
 }
 
@@ -727,6 +740,7 @@ template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f,
 struct CoopSolver {
     int o_lu, o_src;         // scratch of the running solve
     int o_llu, o_lsrc;       // the extrapolation origin's factors (last_linsolver, src/solvers.jl:191-196)
+    int last[2];             // register instantiations: where this lane's rows ended in the latest factorisation (coop_lu_rows)
 };
 ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
     const int a = f.o_lu, b = f.o_src;
@@ -743,7 +757,7 @@ template <int NC> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &
         double a[COOP_REG_SLOTS][NC], res[COOP_REG_SLOTS], tv[COOP_REG_SLOTS][4];
         int pos[COOP_REG_SLOTS];
         (void)coop_evaluate_rows<NC>(c, s, c.O.lz, a, res, tv);
-        (void)coop_lu_rows<NC>(c, s.nn, a, pos);
+        (void)coop_lu_rows<NC>(c, s.nn, a, pos, f.last);
         coop_calc_jp_rows(c, s, tv, pred);
         coop_store_factors<NC>(c, s.nn, a, pos, pred);
     } else {
@@ -791,7 +805,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             });
             double resmax = wv::allmax16(rm);
             if (!finite) resmax = (double)NAN;
-            const bool ok = coop_lu_rows<NC>(c, nn, a, pos);
+            const bool ok = coop_lu_rows<NC>(c, nn, a, pos, f.last);
             COOP_T(c, CT_LU);
             const bool small = resmax < c.A.tol;
             const bool accept = act && finite && ok && small;
@@ -1012,7 +1026,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     long long *rep = A.report + i * RW_WORDS;
     const bool has_sub = H.nsub > 0;
     const GenSub &s = H.sub[0];
-    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0};
+    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}};
     const bool caching = has_sub && A.solver == SOLVER_CACHING_HOMOTOPY;
     double *cache_g = A.cache + i * H.cache_total + (has_sub ? s.c_off : 0);
     for (int k = lig; k < O.total; k += GROUP) W[k] = 0.0;
