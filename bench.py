@@ -462,8 +462,10 @@ def host_buffer_leg(runner, u, N, T, model):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (defaults = the driver's command: the first steps of a fresh batch learn their solution caches and have no measured
+    # wave costs to place by -- a step is 0.27 s, the whole default run about a minute and a half)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="superover_grid",
                     choices=["superover_grid", "diodeclipper_sweep", "superover_montecarlo", "birdie_grid"],
                     help="superover_grid = BASELINE config 3 (the headline, default); diodeclipper_sweep = "
