@@ -855,6 +855,11 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
             err = assert_close(y, yref, rtol=RTOL_SAME)
             assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
+            # a batch of private model images (acme_batch_set_matrices: the image then stays in L2): the same bits
+            rp = ModelRunner(m, N, lib=hip_lib, models=[m] * N)
+            assert rp.kernel_family() == "coop"
+            yp = np.concatenate([rp.run(u[:, :, :50]), rp.run(u[:, :, 50:])], axis=2)
+            assert np.array_equal(y, yp), (name, solver, "private images")
             # every instantiation in every launch shape (waves per block sharing the staged tables / image, instances per
             # wave, image in LDS or in L2 -- by default whatever keeps most instances resident, csrc/acme_api.inc
             # coop_shape; a pinned shape that does not fit is ignored): the same bits
