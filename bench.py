@@ -64,7 +64,23 @@ def grid_inputs(workload, rank, world, n_per_gpu, T):
         amp = 10.0 ** (-2 + 2.5 * (idx // 128) / max(na - 1, 1))
         vol = 0.01 + 0.99 * (idx % 128) / 127.0
         return "birdie_var_176k", vol[:, None], amp
+    if workload == "clipper_chain_20":       # beyond BASELINE: one 20-unknown sub-problem (workload_model), amplitude sweep
+        return None, None, 10.0 ** (-2 + 2.7 * idx / max(total - 1, 1))
     raise ValueError(workload)
+
+
+def workload_model(workload, fixture, solver, fs=FS):
+    """the workload's DiscreteModel: a committed model-block fixture (tests/golden/*.json: outputs of this repository's
+    front end, re-derived by tests/test_frontend.py) or, for clipper_chain_20, derived on the spot (0.2 s).
+    clipper_chain_20 is beyond BASELINE: ONE nonlinear sub-problem of 20 unknowns -- the reference's LU is written for
+    "sizes up to about 60 x 60" (src/solvers.jl:53-54) and nldecompose! leaves such sub-problems whenever a circuit does not
+    decompose -- which runs in the cooperative mid-size kernel (csrc/acme_coop.h); a tenth of a second of audio per step."""
+    from acme_jl_amd.model import DiscreteModel
+    if workload == "clipper_chain_20":
+        from fractions import Fraction
+        from acme_jl_amd import examples
+        return DiscreteModel(examples.clipper_chain(10), Fraction(1, fs), solver, decompose_nonlinearity=False)
+    return DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
 
 
 def montecarlo_models(rank, n_per_gpu, init_on_device=None):
@@ -200,7 +216,7 @@ def _cpu_worker(args):
     # the build that is about to be timed IS the one asked for (refpy caches per resolved path)
     want = os.path.realpath(reflib) if reflib else os.path.realpath(os.path.join(ROOT, "oracle", "libacme_ref.so"))
     assert refpy.lib().acme_path == want, (refpy.lib().acme_path, want)
-    m = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
+    m = workload_model("clipper_chain_20" if fixture is None else "", fixture, solver)
     cold = warm_t = 0.0
     iters = iters_warm = 0
     for u in rows:
@@ -344,17 +360,8 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3):
     fs = 176400 if workload == "birdie_grid" else FS
     T = fs // 10 if workload == "clipper_chain_20" else fs
     solver = HomotopySolver if workload == "birdie_grid" else CachingHomotopySolver
-    if workload == "clipper_chain_20":
-        # beyond BASELINE: ONE nonlinear sub-problem of 20 unknowns (the reference's LU is written for "sizes up to about
-        # 60 x 60", src/solvers.jl:53-54; nldecompose! leaves such sub-problems whenever a circuit does not decompose) --
-        # the cooperative mid-size kernel (csrc/acme_coop.h), a tenth of a second of audio per step
-        from fractions import Fraction
-        from acme_jl_amd import examples
-        model = DiscreteModel(examples.clipper_chain(10), Fraction(1, fs), solver, decompose_nonlinearity=False)
-        pots, amp = None, 10.0 ** np.linspace(-2, 0.7, n)
-    else:
-        fixture, pots, amp = grid_inputs(workload, 0, 1, n, T)
-        model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver)
+    fixture, pots, amp = grid_inputs(workload, 0, 1, n, T)
+    model = workload_model(workload, fixture, solver, fs)
     if workload == "superover_montecarlo":
         batch = montecarlo_models(0, n, init_on_device={"device": local_rank})
         batch.solver = solver
@@ -467,10 +474,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="superover_grid",
-                    choices=["superover_grid", "diodeclipper_sweep", "superover_montecarlo", "birdie_grid"],
+                    choices=["superover_grid", "diodeclipper_sweep", "superover_montecarlo", "birdie_grid", "clipper_chain_20"],
                     help="superover_grid = BASELINE config 3 (the headline, default); diodeclipper_sweep = "
                          "config 2; superover_montecarlo = config 4 (per-instance model blocks); birdie_grid = "
-                         "config 5 (176.4 kHz, 2048 instances per GPU, HomotopySolver unless --solver is given)")
+                         "config 5 (176.4 kHz, 2048 instances per GPU, HomotopySolver unless --solver is given); "
+                         "clipper_chain_20 = beyond BASELINE, one 20-unknown sub-problem on the mid-size kernel, 0.1 s per step")
     ap.add_argument("--instances", type=int, default=None, help="instances per GPU")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short steady-state legs of BASELINE configs 2, 4, 5 (config.other_workloads) that follow the headline")
@@ -524,14 +532,13 @@ def main():
 
     n_per_gpu = args.instances or {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(args.workload, 8192)
     fs = 176400 if args.workload == "birdie_grid" else FS
-    T = args.samples or fs
+    T = args.samples or (fs // 10 if args.workload == "clipper_chain_20" else fs)
     args.solver = args.solver or ("homotopy" if args.workload == "birdie_grid" else "caching")
     fixture, pots, amp = grid_inputs(args.workload, rank, world, n_per_gpu, T)
     # rank 0 owns the model block; everyone else receives it over RCCL (xGMI)
     from acme_jl_amd.model import CachingHomotopySolver, HomotopySolver, SimpleSolver
     solver = {"caching": CachingHomotopySolver, "homotopy": HomotopySolver, "simple": SimpleSolver}[args.solver]
-    model = DiscreteModel.load(os.path.join(ROOT, "tests", "golden", fixture + ".json"), solver=solver) \
-        if rank == 0 else None
+    model = workload_model(args.workload, fixture, solver, fs) if rank == 0 else None
     model = broadcast_model(model, src=0, device=dev) if use_dist else model
 
     setup = {}
@@ -675,6 +682,10 @@ def main():
                  f"per GPU: {n_per_gpu * world // 128} amplitudes 10^(-2..0.5) x 128 vol in linspace(0.01,1), "
                  "1 kHz sine")
                 if args.workload == "birdie_grid" else
+                (f"beyond BASELINE: a chain of 10 diode-clipper stages, undecomposed = ONE nonlinear sub-problem "
+                 f"(nn=20,nq=40,np=10,nx=10,nu=1; acme_jl_amd.examples.clipper_chain), {n_per_gpu}-instance amplitude sweep "
+                 "10mV..5V per GPU, 1 kHz sine: the cooperative mid-size kernel")
+                if args.workload == "clipper_chain_20" else
                 f"examples/diodeclipper.jl, {n_per_gpu}-instance amplitude sweep 10mV..10V per GPU",
                 "instances_per_gpu": n_per_gpu, "samples_per_step": T, "fs": fs,
                 "solver": model.solver,

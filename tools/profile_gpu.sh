@@ -35,7 +35,7 @@ python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import collections, glob, json, os, shlex, sqlite3, sys
 out = sys.argv[1]
 warm = int(os.environ["WARM"])
-sel = "(name like '%acme_run_kernel%' or name like '%acme_lane_kernel%')"
+sel = "(name like '%acme_run_kernel%' or name like '%acme_lane_kernel%' or name like '%acme_coop_kernel%')"
 print("command: python bench.py --no-cpu-baseline --steps %s --warmup %s %s" % (os.environ["NSTEPS"], warm, os.environ.get("BENCH_ARGS", "")))
 print("(steady state: the %d warm-up dispatches of the run kernel are dropped from every figure below)" % warm)
 kern = {}
@@ -44,7 +44,7 @@ for f in sorted(glob.glob(out + "/trace/**/*.db", recursive=True)):
     print("== rocprofv3 --kernel-trace --stats: top kernels (all dispatches)")
     print("%-86s %6s %14s %14s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for r in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 5"):
-        print("%-86s %6d %14.3f %14.3f %8.3f" % (r[0][:86], r[1], r[2] / 1e6, r[3] / 1e6, r[4]))      # (the table holds nanoseconds)
+        print("%-86s %6d %14.3f %14.3f %8.3f" % (r[0][:86], r[1], r[2] / 1e3, r[3] / 1e3, r[4]))      # (the table holds microseconds)
     rows = con.execute("select name, start, end, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x "
                        "from kernels where " + sel + " order by start").fetchall()
     steady = rows[warm:]
@@ -74,7 +74,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     opt = lambda name, default: a[a.index(name) + 1] if name in a else default      # noqa: E731
     wl = opt("--workload", "superover_grid")
     n_def = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(wl, 8192)      # bench.py's defaults
-    t_def = 176400 if wl == "birdie_grid" else 44100
+    t_def = 176400 if wl == "birdie_grid" else 4410 if wl == "clipper_chain_20" else 44100
     try:        # what exactly ran: the traced run's own bench line (solver stack, kernel variant, its kernel_ms)
         line = json.loads(open(out + "/bench_line.json").read().strip().splitlines()[-1])
     except Exception:
