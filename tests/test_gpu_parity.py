@@ -855,6 +855,11 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
             err = assert_close(y, yref, rtol=RTOL_SAME)
             assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
+            # a lone instance (one group of one wave of a four-wave block) and 17 (a ragged second block): the same bits
+            for few in (1, 17):
+                rf = ModelRunner(m, few, lib=hip_lib)
+                yf = np.concatenate([rf.run(u[:few, :, :50]), rf.run(u[:few, :, 50:])], axis=2)
+                assert np.array_equal(y[:few], yf), (name, solver, few)
             # a batch of private model images (acme_batch_set_matrices: the image then stays in L2): the same bits
             rp = ModelRunner(m, N, lib=hip_lib, models=[m] * N)
             assert rp.kernel_family() == "coop"
