@@ -12,7 +12,7 @@ for reg in 1 0; do
 done
 for pin in $COOP_PINS; do      # e.g. COOP_PINS="ACME_COOP_IMGL=0 ACME_COOP_WPB=1"
   echo "== $pin"
-  env $pin timeout 600 python tools/generic_shape_probe.py 8192 1102 "clipper chain, 1" < /dev/null 2>&1 | grep -v amdgpu.ids | tee $out/shape_probe_$pin.txt
+  env ${pin//,/ } timeout 600 python tools/generic_shape_probe.py 8192 1102 "clipper chain, 1" < /dev/null 2>&1 | grep -v amdgpu.ids | tee $out/shape_probe_$pin.txt
 done
 lib=$PWD/build_variants/libacme_hip_cooptiming.so
 if [ -f $lib ]; then
