@@ -867,6 +867,7 @@ def test_emulated_mosfet_polynomial_cap_is_reported_by_the_abi(emu_lib):
     L.acme_model_destroy(mh)
 
 
+@pytest.mark.timeout(900)          # (a kernel that stops converging runs the emulator to its iteration limits: fail, do not crawl)
 def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
     """The cooperative mid-size kernel (csrc/acme_coop.h: one instance per 16 lanes, rows dealt out over the lanes, working
     arrays in LDS) on one sub-problem of 20 / 24 / 32 unknowns: the oracle's outputs and iteration totals on both solver
