@@ -81,10 +81,11 @@ __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
 
 // the mid-size kernel (acme_coop.h): GArgs::coop_wpb waves per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
 // (NC: the factor matrix's columns in registers -- 17 ... 32 unknowns -- or 0: factors in LDS, any size)
-// The any-size instantiation is held to 256 registers: left to itself it took 301 (the accumulation registers as spill
-// space) and then computed zeros whenever a wave carried fewer than four instances -- on the GPU only, at every size
-// (measured; the 256-register build is right at 1, 2 and 4 instances per wave, as are the register instantiations, which
-// tests/test_gpu_parity.py::test_mid_size_kernel checks at every group count).
+// The any-size instantiation is held to 256 registers.  As a one-wave-block kernel, left to itself, it took 301 (the
+// accumulation registers as spill space) and then computed zeros whenever a wave carried fewer than four instances -- on
+// the GPU only, at every size, cause not found; the 256-register build was right.  Since the kernel has 256-thread blocks
+// the unbounded build is right as well (measured once, every group count), but no faster: the bound stays.  Every
+// instantiation is checked at 1, 2 and 4 instances per wave (tests/test_gpu_parity.py::test_mid_size_kernel).
 template <bool IMGL, int NC> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 0 ? 2 : 1)))
 void acme_coop_kernel(GArgs A) {
     extern __shared__ double acme_lds[];
