@@ -12,14 +12,19 @@
 //   LinearSolver    src/solvers.jl:46-132    SimpleSolver   src/solvers.jl:151-236
 //   HomotopySolver  src/solvers.jl:247-302   CachingSolver  src/solvers.jl:319-396 (bounded store, as everywhere here)
 // so outputs and iteration counts are the generic kernel's (and the oracle's) -- only WHO computes an entry differs.
-// What makes it fast: an LDS instruction serves 4 instances x 16 rows; the O(nn^3) elimination's inner loop is three LDS
-// operations per multiply-add with nothing but LDS latency behind it; 12 instances of 20 unknowns are resident per
-// compute unit (12.6 KB of LDS each).
+// Two instantiations (GArgs::coop_nc):
+//   * any size (33 ... 64 unknowns): every working array of an instance in LDS at the generic kernel's offsets; the
+//     elimination walks through LDS, row interchanges are real and kept as the composed gather src[]
+//     (x_permuted[i] = x[src[i]]), which is what solve! applies first (src/solvers.jl:103-109);
+//   * 17 ... 32 unknowns (one kernel per column count, rounded up to four): the running factorisation lives in REGISTERS
+//     from evaluate! to the Newton step, rows never move (a position label stands for the interchanges), only an accepted
+//     iterate's factors go to LDS -- 8.8 KB per instance at 20 unknowns, 16 instances per compute unit: see below
+//     ("the running factorisation in REGISTERS").
+// The waves of a block share one staged copy of the row tables and, if the batch shares its model image, of the image
+// (GArgs::coop_wpb / coop_gpw / coop_imgl: the launch shape, chosen per model by the host, acme_api.inc coop_shape).
 //
 // Control flow is WAVE-UNIFORM throughout (the four instances of a wave iterate together, finished ones ride along with
-// their writes predicated off), as in the tuned kernels: data-dependent trip counts are ballots.  Row interchanges of the
-// partially pivoted LU are real (the rows sit in LDS, not in lanes); the sequence of interchanges is kept as the composed
-// gather src[] (x_permuted[i] = x[src[i]]), which is what solve! applies first (src/solvers.jl:103-109).
+// their writes predicated off), as in the tuned kernels: data-dependent trip counts are ballots.
 //
 // A wave never talks to another wave once the block's shared tables are staged (one barrier).
 #pragma once
