@@ -105,6 +105,7 @@ struct CoopCtx {
     int lig, grp;
     long long i;
     bool valid;
+    bool wr;                 // this row of 16 lanes writes to global memory (false: it mirrors the wave's first row, coop_main)
 #ifdef ACME_COOP_TIMING
     CoopTimer *tm;
 #endif
@@ -421,10 +422,12 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
 // x_i -= F_ij x_j in the order of j), so factors, gather, zero-pivot verdict and solutions are the LDS path's bit for bit.
 constexpr int COOP_REG_SLOTS = 2;
 
-// evaluate!(nleq, z) as coop_evaluate, the rows' residuals, Jacobian rows (columns >= nn: zero) and Jq non-zeros in registers
+// evaluate!(nleq, z) as coop_evaluate, the rows' residuals, Jacobian rows (columns >= nn: zero) and Jq non-zeros in registers.
+// rid: WHICH row of the sub-problem each slot of the lane evaluates (-1: none) -- slot sl's own row lig + 16 sl on the
+// literal path, the row the instance's learnt order puts at that position on the threshold path (coop_gj_rows)
 template <int NC>
 ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, double (&a)[COOP_REG_SLOTS][NC],
-                                 double (&res)[COOP_REG_SLOTS], double (&tvr)[COOP_REG_SLOTS][4]) {
+                                 double (&res)[COOP_REG_SLOTS], double (&tvr)[COOP_REG_SLOTS][4], const int (&rid)[COOP_REG_SLOTS]) {
     constexpr int NS = COOP_REG_SLOTS;
     const GenHeader &H = c.H;
     for (int r = c.lig; r < s.nq; r += GROUP) {
@@ -435,11 +438,11 @@ ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, dou
     const wv::ExpTab etab = wv::load_exp_tab();
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int r = c.lig + GROUP * sl;
+        const int r = rid[sl];
         res[sl] = 0.0;
         for (int t = 0; t < 4; ++t) tvr[sl][t] = 0.0;
         sfor<0, NC>([&](auto jc) ACME_LAMBDA { a[sl][decltype(jc)::value] = 0.0; });
-        if (r < s.nn) {
+        if (r >= 0) {
             RowDesc rd;
             int tc[4];
             coop_rowdesc(c, s.row0 + r, rd, tc);
@@ -473,12 +476,15 @@ ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, dou
     return bad;
 }
 
-// calc_Jp closure with the Jq non-zeros of the latest coop_evaluate_rows, written to the origin's Jp where `pred`
-ACME_DEV void coop_calc_jp_rows(const CoopCtx &c, const GenSub &s, const double (&tvr)[COOP_REG_SLOTS][4], bool pred) {
+// calc_Jp closure with the Jq non-zeros of the latest coop_evaluate_rows (of the rows rid), written to the origin's Jp where
+// `pred` -- row rid[sl] of Jp at row wrow[sl] of the stored matrix (the literal path: the row's own number; the threshold
+// path: the position the row holds, which is where the replayed elimination expects its right-hand side)
+ACME_DEV void coop_calc_jp_rows(const CoopCtx &c, const GenSub &s, const double (&tvr)[COOP_REG_SLOTS][4], bool pred,
+                                const int (&rid)[COOP_REG_SLOTS], const int (&wrow)[COOP_REG_SLOTS]) {
     sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int r = c.lig + GROUP * sl;
-        if (r < s.nn) {
+        const int r = rid[sl];
+        if (r >= 0) {
             const int blk = (s.row0 + r) / GROUP, ln = (s.row0 + r) % GROUP;
             int tc[4];
             for (int t = 0; t < 4; ++t) tc[t] = c.ti[blk * ROWI * GROUP + (3 + t) * GROUP + ln];
@@ -491,7 +497,7 @@ ACME_DEV void coop_calc_jp_rows(const CoopCtx &c, const GenSub &s, const double 
                 for (int u = 0; u < 4; ++u) {
                     double acc = 0.0;
                     for (int t = 0; t < 4; ++t) acc = fma(tvr[sl][t], pv[u][t], acc);
-                    if (pred && j + u < s.np) c.W[c.O.ljp + (j + u) * s.nn + r] = acc;
+                    if (pred && j + u < s.np) c.W[c.O.ljp + (j + u) * s.nn + wrow[sl]] = acc;
                 }
             }
         }
@@ -734,9 +740,126 @@ template <int NC> ACME_DEV void coop_lu_solve_reg(const CoopCtx &c, int n, int o
     wv::wave_fence();
 }
 
+// ---- the THRESHOLD path (THR; 17 ... 32 unknowns): the tuned 16-lane kernels' elimination, two rows per lane ----
+// coop_lu_rows above reproduces the reference's dynamic first-strict-maximum pivoting bit for bit, and pays for it at every
+// step: a search (16-lane reduction), the pivot row's round trip through LDS, an IEEE division -- 40 % of the kernel's
+// cycles (profiles/r5_coop_timing.txt).  The tuned kernels (acme_kernel.h RowLU::solve_inplace) do not look for pivots:
+// an instance keeps the row ORDER of the last factorisation that had to interchange rows -- position p (lane p mod 16,
+// slot p / 16) evaluates row rid of the residual, so that the pivot of step k is where a compile-time DPP broadcast finds
+// it -- and eliminates without a search, above and below the pivot (Gauss-Jordan: no triangular sweeps, the Newton step
+// rides along as a column), with v_rcp_f64 + refinement for 1 / pivot and fused v_fmac_f64_dpp for "broadcast the pivot
+// row's entry, multiply, accumulate".  The order is kept while every multiplier of a row still waiting to be the pivot
+// satisfies |l| <= 8 (threshold partial pivoting, |pivot| >= max / 8: src/solvers.jl:58-78 is the case 1; the stated
+// deviation of DESIGN a-13); an instance that trips the threshold -- or meets a zero pivot -- evaluates again, runs
+// coop_lu_rows (the reference's pivoting) to LEARN the order, adopts it and eliminates again.  Either way the result is
+// that of a valid LU of the same Jacobian with bounded growth: Newton steps agree with the reference's to rounding, the
+// accepted iterate is decided by the residual test alone.
+// What is kept of the factorisation at an extrapolation origin is the RECORDED elimination: column k of a row holds minus
+// its multiplier of step k (0 in the pivot row itself), one more number its 1 / pivot; applied to another right-hand
+// side (coop_replay_gj) it is the same linear map.  Unknown k comes out at position k whatever the row order was.
+constexpr double COOP_PIVOT_THRESHOLD = 8.0;
+
+// [A | rhs] -> A^-1 rhs (entry k at position k; dinv applied), a: the recorded elimination, dinv: the rows' 1 / pivot.
+// Returns (per lane) whether its instance must not trust the result: threshold tripped, zero or non-finite pivot.
+template <int NC>
+ACME_DEV bool coop_gj_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][NC], double (&rhs)[COOP_REG_SLOTS], double (&dinv)[COOP_REG_SLOTS]) {
+    static_assert(COOP_REG_SLOTS == 2 && NC % 4 == 0 && NC <= 2 * GROUP, "two rows per lane");
+    double vmx[2] = {0.0, 0.0}, frz[2] = {0.0, 0.0};
+    dinv[0] = dinv[1] = 1.0;
+    sfor<0, NC>([&](auto kc) ACME_LAMBDA {
+        constexpr int k = decltype(kc)::value;
+        constexpr int ks = k / GROUP, os = 1 - ks, kl = k % GROUP;
+        if (k <= NC - 4 || k < n) {          // (uniform; only the last three steps of an instantiation can be beyond the model)
+            wv::gj2_head<kl>(a[ks][k], a[os][k], dinv[ks], vmx[ks], vmx[os], frz[ks]);
+            constexpr int M = NC - k;                           // the columns right of the pivot, and the right-hand side
+            double *kp[M], *op[M];
+            sfor<k + 1, NC>([&](auto jc) ACME_LAMBDA {
+                constexpr int j = decltype(jc)::value;
+                kp[j - k - 1] = &a[ks][j];
+                op[j - k - 1] = &a[os][j];
+            });
+            kp[M - 1] = &rhs[ks];
+            op[M - 1] = &rhs[os];
+            wv::gj2_update<kl>(a[ks][k], a[os][k], kp, op);
+        }
+    });
+    bool trip = false;
+    sfor<0, 2>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        rhs[sl] *= dinv[sl];
+        const bool real = c.lig + GROUP * sl < n;
+        // a zero pivot (exactly singular in this order) or a NaN turns the row's result into NaN, an infinite pivot leaves
+        // 1 / pivot = 0 behind (RowLU::solve_inplace)
+        trip = trip || (real && (frz[sl] > COOP_PIVOT_THRESHOLD || !(rhs[sl] * 0.0 == 0.0) || dinv[sl] == 0.0));
+    });
+    return coop_any(c, trip);
+}
+
+// an accepted iterate's recorded elimination into the origin's matrix in LDS (row p: position p's multipliers, behind them
+// its 1 / pivot), for the instances with `pred`
+template <int NC>
+ACME_DEV void coop_store_gj(const CoopCtx &c, int n, const double (&a)[COOP_REG_SLOTS][NC], const double (&dinv)[COOP_REG_SLOTS], bool pred) {
+    double *F = c.W + c.O.llu;
+    sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int p = c.lig + GROUP * sl;
+        if (pred && p < n) {
+            sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
+                constexpr int g = decltype(gc)::value;
+                wv::st2(F + p * c.O.ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
+            });
+            F[p * c.O.ld + NC] = dinv[sl];
+        }
+    });
+    wv::wave_fence();
+}
+
+// x <- A^-1 x with the elimination recorded at the origin (x at w_x, entry p the right-hand side of the row at position p
+// on the way in, unknown p on the way out)
+template <int NC> ACME_DEV void coop_replay_gj(const CoopCtx &c, int n, int w_x) {
+    double *W = c.W;
+    const double *F = W + c.O.llu;
+    double m[2][NC], x[2], dinv[2];
+    bool real[2];
+    sfor<0, 2>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int p = c.lig + GROUP * sl;
+        real[sl] = p < n;
+        x[sl] = real[sl] ? W[w_x + p] : 0.0;
+        dinv[sl] = real[sl] ? F[p * c.O.ld + NC] : 0.0;
+        sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            wv::pair_t v{0.0, 0.0};
+            if (real[sl]) v = wv::ld2(F + p * c.O.ld + 2 * g);
+            m[sl][2 * g] = v.lo;
+            m[sl][2 * g + 1] = v.hi;
+        });
+    });
+    // (steps in runs of four: whole runs are inside the model for all but the last, and inside one slot)
+    sfor<0, NC / 4>([&](auto gc) ACME_LAMBDA {
+        constexpr int k0 = 4 * decltype(gc)::value;
+        constexpr int ks = k0 / GROUP, os = 1 - ks;
+        if (k0 + 4 < NC || k0 + 4 <= n) {
+            wv::replay2_seg<k0, 4, k0>(x[ks], x[os], m[ks], m[os]);
+        } else {
+            sfor<0, 3>([&](auto uc) ACME_LAMBDA {
+                constexpr int k = k0 + decltype(uc)::value;
+                if (k < n) wv::replay2_seg<k, 1, k>(x[ks], x[os], m[ks], m[os]);
+            });
+        }
+    });
+    wv::wave_fence();
+    sfor<0, 2>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        if (real[sl]) W[w_x + c.lig + GROUP * sl] = x[sl] * dinv[sl];
+    });
+    wv::wave_fence();
+}
+
 // the extrapolation's solve! of a kernel instantiated for NC columns (0: the LDS version, any size)
-template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
-    if constexpr (NC > 0) coop_lu_solve_reg<NC>(c, n, o_f, o_src, w_x);
+template <int NC, bool THR> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
+    if constexpr (NC > 0 && THR) coop_replay_gj<NC>(c, n, w_x);
+    else if constexpr (NC > 0) coop_lu_solve_reg<NC>(c, n, o_f, o_src, w_x);
     else coop_lu_solve(c, n, o_f, o_src, w_x);
 }
 
@@ -746,6 +869,10 @@ struct CoopSolver {
     int o_lu, o_src;         // scratch of the running solve
     int o_llu, o_lsrc;       // the extrapolation origin's factors (last_linsolver, src/solvers.jl:191-196)
     int last[2];             // register instantiations: where this lane's rows ended in the latest factorisation (coop_lu_rows)
+    int rid[2];              // ... which rows of the sub-problem the lane's two slots hold (-1: none).  Literal path: slot
+                             // sl's own row lig + 16 sl, for good; threshold path: the instance's learnt row order
+    bool fresh;              // threshold path: the origin (lp, lz) has no recorded elimination yet (launch start): the next
+                             // solve linearises there first
 };
 ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
     const int a = f.o_lu, b = f.o_src;
@@ -755,15 +882,82 @@ ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
     f.o_lsrc = pred ? b : f.o_lsrc;
 }
 
+// Threshold path: evaluate!(nleq, z at w_z) and the elimination of [J | res] in the instance's current row order; where
+// that order trips the pivot threshold (for the instances with `act`: nobody else's result is looked at) the rows are
+// evaluated again, the reference's partially pivoted LU (coop_lu_rows) says where each row belongs, the instance adopts
+// that order and everything is done once more.  ONE copy of evaluate! and of the elimination in the code: the three
+// passes are trips of a loop.
+//   out: a / dinv the recorded elimination, res = J^-1 res (unknown p at position p), tv the rows' Jq non-zeros,
+//        resmax = max |res| before the solve (NaN: something was not finite), ok = false where the matrix is singular
+//        (coop_lu_rows met an exactly zero pivot: src/solvers.jl:80-83) -- both per instance
+template <int NC>
+ACME_DEV void coop_linearize(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_z, bool act, double (&a)[COOP_REG_SLOTS][NC],
+                             double (&res)[COOP_REG_SLOTS], double (&tv)[COOP_REG_SLOTS][4], double (&dinv)[COOP_REG_SLOTS],
+                             double &resmax, bool &ok) {
+    constexpr int NS = COOP_REG_SLOTS;
+    const int nn = s.nn;
+    int phase = 0;          // 0: the usual pass; 1: learning the order; 2: once more in the new order
+    bool learn = false;     // this instance is adopting a new order
+    ok = true;
+    for (;;) {
+        const bool bad = coop_evaluate_rows<NC>(c, s, w_z, a, res, tv, f.rid);
+        COOP_T(c, CT_EVAL);
+        if (phase == 1) {
+            int pos[NS];
+            const bool okl = coop_lu_rows<NC>(c, nn, a, pos, f.last);
+            ok = learn ? okl : ok;
+            // the row that ended at position p moves to position p (through the x_j hand-off buffer, as integers)
+            int *ob = reinterpret_cast<int *>(c.W + c.O.xb);
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                if (f.rid[sl] >= 0) ob[pos[sl]] = f.rid[sl];
+            });
+            wv::wave_fence();
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const int p = c.lig + GROUP * sl;
+                if (learn && p < nn) {
+                    f.rid[sl] = ob[p];
+                    f.last[sl] = p;          // (where this row would end if the same matrix were factored again)
+                }
+            });
+            wv::wave_fence();
+            COOP_T(c, CT_LU);
+            phase = 2;
+            continue;
+        }
+        const bool finite = !coop_any(c, bad);
+        double rm = 0.0;
+        sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+            constexpr int sl = decltype(sc)::value;
+            const double v = fabs(res[sl]);
+            if (f.rid[sl] >= 0 && v > rm) rm = v;
+        });
+        resmax = wv::allmax16(rm);
+        if (!finite) resmax = (double)NAN;
+        const bool trip = coop_gj_rows<NC>(c, nn, a, res, dinv);
+        COOP_T(c, CT_LU);
+        if (phase == 0) {
+            learn = act && finite && trip;
+            if (ACME_USUAL(wv::ballot(learn) == 0ull)) break;
+            phase = 1;
+            continue;
+        }
+        ok = ok && !(learn && trip);          // (cannot happen behind partial pivoting short of a singular matrix)
+        break;
+    }
+}
+
 // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196) at (w_lp, w_lz) for the instances with `pred`
-template <int NC> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
+template <int NC, bool THR> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
+    static_assert(!(NC > 0 && THR), "the threshold path re-linearises inside coop_simple_solve (`reorig`): one copy of the pass");
     coop_set_p(c, s, c.O.lp);
     if constexpr (NC > 0) {
         double a[COOP_REG_SLOTS][NC], res[COOP_REG_SLOTS], tv[COOP_REG_SLOTS][4];
         int pos[COOP_REG_SLOTS];
-        (void)coop_evaluate_rows<NC>(c, s, c.O.lz, a, res, tv);
+        (void)coop_evaluate_rows<NC>(c, s, c.O.lz, a, res, tv, f.rid);
         (void)coop_lu_rows<NC>(c, s.nn, a, pos, f.last);
-        coop_calc_jp_rows(c, s, tv, pred);
+        coop_calc_jp_rows(c, s, tv, pred, f.rid, f.rid);
         coop_store_factors<NC>(c, s.nn, a, pos, pred);
     } else {
         (void)coop_evaluate(c, s, c.O.lz, f.o_lu);
@@ -774,32 +968,90 @@ template <int NC> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &
 }
 
 // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`: p at w_p, z left in w_zz; returns
-// hasconverged, needediterations in its
-template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
+// hasconverged, needediterations in its.
+// reorig (threshold path only): set_extrapolation_origin(solver, last_p, last_z) (src/solvers.jl:183-196) first, for these
+// instances -- their origin was replaced by a stored solution (coop_cached_solve) or has no recorded elimination yet (launch
+// start).  It is a pass of the SAME loop as the Newton iterations: evaluate!, the elimination and the re-learning exist
+// once in the kernel (what Shape::ONELOOP is to the tuned kernels), not once per caller.
+template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its, bool reorig = false) {
     const GenHeader &H = c.H;
     double *W = c.W;
     const int nn = s.nn, np = s.np;
     COOP_T(c, CT_REST);
-    coop_set_p(c, s, w_p);
-    COOP_T(c, CT_SETP);
-    // z <- last_z - last_J \ (last_Jp (p - last_p))
-    for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
-    wv::wave_fence();
-    coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
-    for (int r = c.lig; r < nn; r += GROUP)
-        if (need) W[c.O.zz + r] = W[c.O.lz + r] - W[c.O.tmp + r];
-    wv::wave_fence();
-    COOP_T(c, CT_EXTRAP);
+    // the start: z <- last_z - last_J \ (last_Jp (p - last_p))  (src/solvers.jl:209-215)
+    auto start = [&]() ACME_LAMBDA {
+        coop_set_p(c, s, w_p);
+        COOP_T(c, CT_SETP);
+        for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
+        wv::wave_fence();
+        coop_backsolve<NC, THR>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
+        for (int r = c.lig; r < nn; r += GROUP)
+            if (need) W[c.O.zz + r] = W[c.O.lz + r] - W[c.O.tmp + r];
+        wv::wave_fence();
+        COOP_T(c, CT_EXTRAP);
+    };
     bool act = need, conv = false;
     double reslast = 0.0;
     its = 0;
-    if constexpr (NC > 0) {
+    if constexpr (NC > 0 && THR) {
+        constexpr int NS = COOP_REG_SLOTS;
+        const int wrow[NS] = {c.lig, c.lig + GROUP};
+        int stage = wv::ballot(reorig) != 0ull ? 0 : 1;          // 0: re-linearising at the origin; 1: the start is due; 2: Newton
+        for (;;) {
+            if (stage == 0) {
+                coop_set_p(c, s, c.O.lp);
+            } else {
+                if (stage == 1) {
+                    start();
+                    stage = 2;
+                }
+                if (wv::ballot(act) == 0ull) break;
+                its += act ? 1 : 0;
+            }
+            const bool origin = stage == 0;
+            double a[NS][NC], res[NS], tv[NS][4], dinv[NS], resmax;
+            bool ok;
+            coop_linearize<NC>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, a, res, tv, dinv, resmax, ok);
+            const bool finite = resmax == resmax;
+            const bool small = resmax < c.A.tol;
+            const bool accept = !origin && act && finite && ok && small;
+            const bool step = !origin && act && finite && ok && !small;
+            reslast = (!origin && act) ? resmax : reslast;
+            // the Newton step came out of the elimination: unknown p at position p
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const int p = c.lig + GROUP * sl;
+                if (step && p < nn) W[c.O.zz + p] -= res[sl];
+            });
+            COOP_T(c, CT_SOLVE);
+            // an accepted iterate: its recorded elimination, Jp, p and z become the extrapolation origin; an origin that
+            // is being re-linearised keeps its p and z
+            const bool rec = origin ? reorig : accept;
+            if (wv::ballot(rec) != 0ull) {
+                coop_calc_jp_rows(c, s, tv, rec, f.rid, wrow);
+                coop_store_gj<NC>(c, nn, a, dinv, rec);
+                for (int j = c.lig; j < np; j += GROUP)
+                    if (accept) W[c.O.lp + j] = W[w_p + j];
+                for (int r = c.lig; r < nn; r += GROUP)
+                    if (accept) W[c.O.lz + r] = W[c.O.zz + r];
+            }
+            wv::wave_fence();
+            COOP_T(c, CT_ACCEPT);
+            if (origin) {
+                stage = 1;
+                continue;
+            }
+            conv = conv || accept;
+            act = step && its < c.A.maxiter;
+        }
+    } else if constexpr (NC > 0) {
+        start();
         constexpr int NS = COOP_REG_SLOTS;
         while (wv::ballot(act) != 0ull) {
             its += act ? 1 : 0;
             double a[NS][NC], res[NS], tv[NS][4];
             int pos[NS];
-            const bool bad = coop_evaluate_rows<NC>(c, s, c.O.zz, a, res, tv);
+            const bool bad = coop_evaluate_rows<NC>(c, s, c.O.zz, a, res, tv, f.rid);
             COOP_T(c, CT_EVAL);
             const bool finite = !coop_any(c, bad);
             double rm = 0.0;
@@ -827,7 +1079,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             COOP_T(c, CT_SOLVE);
             // an accepted iterate: its factors, Jp, p and z become the extrapolation origin
             if (wv::ballot(accept) != 0ull) {
-                coop_calc_jp_rows(c, s, tv, accept);
+                coop_calc_jp_rows(c, s, tv, accept, f.rid, f.rid);
                 coop_store_factors<NC>(c, nn, a, pos, accept);
                 for (int j = c.lig; j < np; j += GROUP)
                     if (accept) W[c.O.lp + j] = W[w_p + j];
@@ -840,6 +1092,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             act = step && its < c.A.maxiter;
         }
     } else {
+        start();
         while (wv::ballot(act) != 0ull) {
             its += act ? 1 : 0;
             const bool bad = coop_evaluate(c, s, c.O.zz, f.o_lu);
@@ -861,7 +1114,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             // the Newton step (for everyone; only the stepping instances keep it)
             for (int r = c.lig; r < nn; r += GROUP) W[c.O.dz + r] = W[c.O.res + r];
             wv::wave_fence();
-            coop_backsolve<NC>(c, nn, f.o_lu, f.o_src, c.O.dz);
+            coop_backsolve<NC, THR>(c, nn, f.o_lu, f.o_src, c.O.dz);
             for (int r = c.lig; r < nn; r += GROUP)
                 if (step) W[c.O.zz + r] -= W[c.O.dz + r];
             COOP_T(c, CT_SOLVE);
@@ -885,13 +1138,15 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
 }
 
 // solve(::CachingSolver, p) (src/solvers.jl:347-396) with the bounded store (lane e looks at stored solution e)
-template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
+template <int NC, bool THR> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
     double *W = c.W;
     const int nn = s.nn, np = s.np;
     double *cp = c.Cp;                                                                       // LDS (coop_main loads / stores it)
     int *meta = reinterpret_cast<int *>(cp + np * CACHE);
     double *cz = c.A.cache + (c.valid ? c.i : 0) * c.H.cache_total + s.c_off + np * CACHE + 2;   // the stored z's: HBM
     const bool caching = c.A.solver == SOLVER_CACHING_HOMOTOPY;
+    bool reorig = f.fresh;          // (threshold path: the origin still lacks its recorded elimination at launch start)
+    f.fresh = false;
     if (caching) {
         static_assert(CACHE == GROUP, "one stored solution per lane");
         double best = 0.0, d = 0.0;
@@ -915,11 +1170,12 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
             for (int r = c.lig; r < nn; r += GROUP)
                 if (hit) W[c.O.lz + r] = cz[e * nn + r];
             wv::wave_fence();
-            coop_set_origin<NC>(c, s, f, hit);
+            if constexpr (NC > 0 && THR) reorig = reorig || hit;          // (a pass of coop_simple_solve's loop)
+            else coop_set_origin<NC, THR>(c, s, f, hit);
         }
     }
     COOP_T(c, CT_LOOKUP);
-    const bool conv = coop_simple_solve<NC>(c, s, f, w_p, need, its);
+    const bool conv = coop_simple_solve<NC, THR>(c, s, f, w_p, need, its, reorig);
     if (caching) {
         const bool keep = need && conv && its > 5;
         if (wv::ballot(keep) != 0ull) {
@@ -929,7 +1185,7 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
             for (int j = c.lig; j < np; j += GROUP)
                 if (keep) cp[j * CACHE + slot] = W[w_p + j];
             for (int r = c.lig; r < nn; r += GROUP)
-                if (keep) cz[slot * nn + r] = W[c.O.zz + r];
+                if (keep && c.wr) cz[slot * nn + r] = W[c.O.zz + r];
             if (keep && c.lig == 0) {
                 meta[0] = count < CACHE ? count + 1 : count;
                 meta[1] = count < CACHE ? head : (head + 1) & (CACHE - 1);
@@ -943,7 +1199,7 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
 // solve(::HomotopySolver, p) (src/solvers.jl:268-296); p at w_p of the header.  ONE loop whose first pass is the direct
 // attempt (at w_p) and whose later passes are the bisection's (at w_pa): one inlined copy of the solver stack in the kernel
 // instead of two (what Shape::ONELOOP is to the tuned kernels: half the code for the instruction cache to hold).
-template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool need0, int &its_total) {
+template <int NC, bool THR> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool need0, int &its_total) {
     const GenHeader &H = c.H;
     double *W = c.W;
     bool conv = false, need = need0, direct = true;
@@ -952,7 +1208,7 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
     its_total = 0;
     do {
         int its;
-        const bool cv = coop_cached_solve<NC>(c, s, f, w_src, need, its);
+        const bool cv = coop_cached_solve<NC, THR>(c, s, f, w_src, need, its);
         its_total += need ? its : 0;
         conv = need ? cv : conv;
         if (direct) {
@@ -994,7 +1250,7 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
 // wave has its instances' workspaces.  A dependent load from L2 costs a lone wave ~1 us, and evaluate! alone chains five of
 // them: with four waves to a block the image of a 20-unknown model fits beside 16 instances' workspaces.  After the one
 // barrier behind the staging a wave never talks to another.
-template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_in_block, int wave_global, int lane) {
+template <bool IMGL, int NC, bool THR> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_in_block, int wave_global, int lane) {
     const GenHeader &H = *A.H;
     const int lig = lane & (GROUP - 1), grp = lane >> 4;
     const int gpw = A.coop_gpw, wpb = A.coop_wpb;
@@ -1015,13 +1271,25 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     if (wpb > 1) wv::block_sync();
     else wv::wave_fence();
     const long long slot = (long long)wave_global * gpw + grp;
-    const bool valid = grp < gpw && slot < A.n_inst;
-    if (!valid) return;      // (a row of 16 lanes without an instance leaves: nothing below crosses the rows of a wave)
-    const long long i = slot;
+    // A row of 16 lanes WITHOUT an instance of its own (a wave carrying fewer than four; the last wave of a batch) does not
+    // leave: it rides along as a MIRROR of the wave's first row -- the same instance, the same workspace in LDS, hence the
+    // same values in every register and the same (redundant) LDS writes -- with its writes to global memory switched off
+    // (`wr`).  The wave then runs with all 64 lanes from the first instruction to the last.  Leaving early (round 5) put the
+    // whole solver under a partial EXEC mask, and the any-size instantiation, built without its register bound, then
+    // computed zeros whenever a wave carried fewer than four instances (tools/zeros_probe.py): with every lane
+    // active that build is right, whatever the register allocation.  (A wave whose FIRST row has no instance has none at all
+    // and leaves as a whole.)
+    const bool wr = grp < gpw && slot < A.n_inst;
+    if ((long long)wave_global * gpw >= A.n_inst) return;          // (a surplus wave of the last block: all 64 lanes leave)
+    // (the CPU wave emulator of the tests runs the lanes of a wave one after the other between rendezvous: a mirror would
+    // apply every LDS read-modify-write a second time there -- its rows leave instead, it has no EXEC mask to get wrong)
+    if (!wr && !wv::lockstep()) return;
+    const bool valid = true;
+    const long long i = wr ? slot : (long long)wave_global * gpw;
     const CoopOff O = coop_offsets(H, NC);
-    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)(wave_in_block * gpw + grp) * coop_inst_doubles(H, NC);
+    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)(wave_in_block * gpw + (wr ? grp : 0)) * coop_inst_doubles(H, NC);
     double *Cp = W + ((O.total + 1) & ~1);
-    CoopCtx c{A, H, O, IMGL ? img : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid};
+    CoopCtx c{A, H, O, IMGL ? img : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid, wr};
 #ifdef ACME_COOP_TIMING
     CoopTimer tmr{};
     tmr.mark = (long long)__builtin_readcyclecounter();
@@ -1031,7 +1299,14 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     long long *rep = A.report + i * RW_WORDS;
     const bool has_sub = H.nsub > 0;
     const GenSub &s = H.sub[0];
-    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}};
+    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}, {-1, -1}, NC > 0 && THR};
+    // the rows the lane's two slots hold: their own (literal path), or what the instance's order -- learnt in earlier
+    // launches, GArgs::coop_order -- puts at the slots' positions (threshold path)
+    if constexpr (NC > 0)
+        for (int sl = 0; sl < 2; ++sl) {
+            const int p = lig + GROUP * sl;
+            f.rid[sl] = (has_sub && p < s.nn) ? (THR ? A.coop_order[i * (2 * GROUP) + p] : p) : -1;
+        }
     const bool caching = has_sub && A.solver == SOLVER_CACHING_HOMOTOPY;
     double *cache_g = A.cache + i * H.cache_total + (has_sub ? s.c_off : 0);
     for (int k = lig; k < O.total; k += GROUP) W[k] = 0.0;
@@ -1044,7 +1319,8 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) Cp[k] = cache_g[k];
     }
     wv::wave_fence();
-    if (has_sub) coop_set_origin<NC>(c, s, f, true);
+    if constexpr (!(NC > 0 && THR))
+        if (has_sub) coop_set_origin<NC, THR>(c, s, f, true);
     bool dead = rep[RW_FIRST_NONFINITE] >= 0;
     long long it_total = 0, it_max = 0;
     // this sample's inputs sit in LDS (GenHeader::w_u); the next sample's are requested a sample ahead (HBM latency)
@@ -1079,14 +1355,14 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             wv::wave_fence();
             COOP_T(c, CT_PRE);
             int its;
-            const bool conv = coop_homotopy_solve<NC>(c, s, f, alive, its);
+            const bool conv = coop_homotopy_solve<NC, THR>(c, s, f, alive, its);
             its_sample = alive ? its : 0;
             const bool failed = alive && !conv;
             if (wv::ballot(failed) != 0ull) {            // the policy of step! (src/ACME.jl:688-694)
                 bool nf = false;
                 for (int r = lig; r < s.nn; r += GROUP) nf = nf || !(W[c.O.zz + r] * 0.0 == 0.0);
                 const bool zfinite = !coop_any(c, nf);
-                if (failed && lig == 0) {
+                if (failed && lig == 0 && wr) {
                     if (zfinite) {
                         rep[RW_NWARN] += 1;
                         if (rep[RW_FIRST_NONCONV] < 0) rep[RW_FIRST_NONCONV] = A.sample_base + n;
@@ -1116,7 +1392,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             if (isx) {
                 if (live) W[c.O.xn + r] = acc;
             } else {
-                yn[r] = live ? acc : (double)NAN;
+                if (wr) yn[r] = live ? acc : (double)NAN;
             }
         }
         wv::wave_fence();
@@ -1126,17 +1402,21 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         COOP_T(c, CT_XY);
     }
 #ifdef ACME_COOP_TIMING
-    if (lig == 0 && A.T >= CT_N && H.ny > 0)
+    if (lig == 0 && wr && A.T >= CT_N && H.ny > 0)
         for (int k = 0; k < CT_N; ++k) A.y[(i * A.T + k) * H.ny] = (double)tmr.t[k];
 #endif
-    for (int k = lig; k < H.nx; k += GROUP) st[k] = W[c.O.x + k];
-    if (has_sub) {
+    if (wr)
+        for (int k = lig; k < H.nx; k += GROUP) st[k] = W[c.O.x + k];
+    if (has_sub && wr) {
         for (int j = lig; j < s.np; j += GROUP) st[H.nx + s.poff + j] = W[c.O.lp + j];
         for (int r = lig; r < s.nn; r += GROUP) st[H.nx + H.npt + s.zoff + r] = W[c.O.lz + r];
         if (caching)
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) cache_g[k] = Cp[k];
+        if constexpr (NC > 0 && THR)          // (a run split over several launches repeats the one-launch arithmetic)
+            for (int sl = 0; sl < 2; ++sl)
+                if (lig + GROUP * sl < s.nn) A.coop_order[i * (2 * GROUP) + lig + GROUP * sl] = f.rid[sl];
     }
-    if (lig == 0) {
+    if (lig == 0 && wr) {
         rep[RW_ITERS_TOTAL] += it_total;
         if (it_max > rep[RW_ITERS_MAX]) rep[RW_ITERS_MAX] = it_max;
     }

@@ -18,7 +18,7 @@
 #include "../../include/acme_hip.h"
 #include "acme_kernels.h"
 #include "acme_pack.h"
-#include "acme_coop.h"
+#include "acme_coop_kernel.h"
 
 using namespace acme;
 
@@ -77,20 +77,6 @@ static const std::vector<KernelEntry> &kernel_table() {
 __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
     const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
     if (i < A.n_inst) gen_main(A, i);
-}
-
-// the mid-size kernel (acme_coop.h): GArgs::coop_wpb waves per block, GArgs::coop_gpw instances per wave, their working arrays in LDS
-// (NC: the factor matrix's columns in registers -- 17 ... 32 unknowns -- or 0: factors in LDS, any size)
-// The any-size instantiation is held to 256 registers.  As a one-wave-block kernel, left to itself, it took 301 (the
-// accumulation registers as spill space) and then computed zeros whenever a wave carried fewer than four instances -- on
-// the GPU only, at every size, cause not found; the 256-register build was right.  Since the kernel has 256-thread blocks
-// the unbounded build is right as well (measured once, every group count), but no faster: the bound stays.  Every
-// instantiation is checked at 1, 2 and 4 instances per wave (tests/test_gpu_parity.py::test_mid_size_kernel).
-template <bool IMGL, int NC> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 0 ? 2 : 1)))
-void acme_coop_kernel(GArgs A) {
-    extern __shared__ double acme_lds[];
-    const int wave = (int)threadIdx.x >> 6;
-    coop_main<IMGL, NC>(A, acme_lds, wave, (int)blockIdx.x * A.coop_wpb + wave, (int)threadIdx.x & 63);
 }
 
 // placement of the waves by their measured cost (acme_balance.h): one thread per wave
@@ -162,28 +148,27 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)h
 static inline int launch_generic(const GArgs &A, stream_t st) {
     return ACME_LAUNCH(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
 }
-template <bool IMGL, int NC> static inline int launch_coop_as(const GArgs &A, size_t lds_bytes, stream_t st) {
-    static size_t allowed = 0;               // (dynamic LDS beyond 64 KB has to be asked for, once per size)
-    if (lds_bytes > allowed) {
-        const int rc = set_max_lds((const void *)acme_coop_kernel<IMGL, NC>, (int)lds_bytes);
-        if (rc != 0) return rc;
-        allowed = lds_bytes;
+// the entry point of a launch shape (GArgs::coop_imgl / coop_nc / coop_thr)
+static inline const void *coop_fn(const GArgs &A) {
+    const int thr = A.coop_thr != 0 && A.coop_nc > 0;
+    switch (A.coop_nc) {
+    case 20: return acme_coop_fn_nc20(A.coop_imgl, thr);
+    case 24: return acme_coop_fn_nc24(A.coop_imgl, thr);
+    case 28: return acme_coop_fn_nc28(A.coop_imgl, thr);
+    case 32: return acme_coop_fn_nc32(A.coop_imgl, thr);
+    default: return A.coop_imgl ? (const void *)acme_coop_kernel<true, 0, false> : (const void *)acme_coop_kernel<false, 0, false>;
     }
+}
+// dynamic LDS beyond 64 KB has to be asked for: per entry point and DEVICE (the caller is on the batch's device), at batch
+// creation and whenever the batch's launch shape changes -- not from the launch path, which worker threads of several
+// batches share
+static inline int coop_prepare(const GArgs &A, size_t lds_bytes) { return set_max_lds(coop_fn(A), (int)lds_bytes); }
+static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t st) {
     const long long waves = (A.n_inst + A.coop_gpw - 1) / A.coop_gpw;
     const dim3 grid((unsigned)((waves + A.coop_wpb - 1) / A.coop_wpb));
-    return ACME_LAUNCH((acme_coop_kernel<IMGL, NC>), grid, dim3(64 * A.coop_wpb), lds_bytes, st, A);
-}
-template <bool IMGL> static inline int launch_coop_img(const GArgs &A, size_t lds_bytes, stream_t st) {
-    switch (A.coop_nc) {
-    case 20: return launch_coop_as<IMGL, 20>(A, lds_bytes, st);
-    case 24: return launch_coop_as<IMGL, 24>(A, lds_bytes, st);
-    case 28: return launch_coop_as<IMGL, 28>(A, lds_bytes, st);
-    case 32: return launch_coop_as<IMGL, 32>(A, lds_bytes, st);
-    default: return launch_coop_as<IMGL, 0>(A, lds_bytes, st);
-    }
-}
-static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t st) {
-    return A.coop_imgl != 0 ? launch_coop_img<true>(A, lds_bytes, st) : launch_coop_img<false>(A, lds_bytes, st);
+    GArgs args = A;
+    void *params[] = {&args};
+    return ACME_LAUNCH_FN(coop_fn(A), grid, dim3(64 * A.coop_wpb), lds_bytes, st, params);
 }
 static inline int launch_balance(const BalArgs &A, stream_t st) {
     const unsigned g = (unsigned)((A.nu + 255) / 256);

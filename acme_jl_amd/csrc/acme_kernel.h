@@ -1661,6 +1661,7 @@ template <class S, int MODE = MODE_RUN, bool LOW = false> ACME_DEV void wave_mai
             bool finite, ok, small;
             double dz;
             linearize(z, act, actm, false, finite, ok, small, dz);
+            ACME_DBG("newton it %d lane %d act %d z %.17g res %.17g dz %.17g finite %d ok %d small %d", its, lane, (int)act, z, res, dz, (int)finite, (int)ok, (int)small);
             const bool want = act && finite && ok && small;
             const bool stop_bad = act && (!finite || !ok);
             const bool step = act && !stop_bad && !want;

@@ -47,10 +47,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void acme_lane_kernel(KArgs A) {
     lane_main<S>(A, acme_lds);
 }
 
-// A launch's status.  hipGetLastError() returns -- and clears -- the last error ANY earlier call on this thread recorded
-// (a page-locking that was refused, an unregister of memory the caller had already freed: tolerated failures of the
-// host-buffer path), so the record is cleared before the launch: what is read after it is the launch's own.
-#define ACME_LAUNCH(...) ({ (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); (int)hipGetLastError(); })
+// A launch's status: hipGetLastError() right behind it.  The record is NOT cleared beforehand: the tolerated
+// failures of the host-buffer path (a page-locking that was refused, an unregister of memory the caller had already freed)
+// clear it where they are tolerated (be::tolerated), so whatever else an earlier call on this thread left there is a real
+// fault and is reported by the launch that finds it.
+#define ACME_LAUNCH(...) ({ hipLaunchKernelGGL(__VA_ARGS__); (int)hipGetLastError(); })
+// ... of an entry point chosen at run time (the mid-size kernel's instantiations): params = {&args}
+#define ACME_LAUNCH_FN(fn, grid, block, lds, st, params) ({ (void)hipLaunchKernel((fn), (grid), (block), (params), (lds), (st)); (int)hipGetLastError(); })
 
 // the three 16-lane kernels of one shape in one placement (LDS / LOW): entry points for
 // hipFuncSetAttribute and launchers

@@ -10,6 +10,13 @@
 
 namespace wv {
 
+// the 64 lanes of a wave execute every instruction together (the emulator's run one after the other between rendezvous)
+// (-DACME_COOP_NO_MIRROR: a developer switch of the mid-size kernel, A/B of its mirror rows against rows that leave)
+#ifdef ACME_COOP_NO_MIRROR
+ACME_DEV constexpr bool lockstep() { return false; }
+#else
+ACME_DEV constexpr bool lockstep() { return true; }
+#endif
 ACME_DEV int tid() { return (int)threadIdx.x; }
 ACME_DEV int bid() { return (int)blockIdx.x; }
 ACME_DEV void block_sync() { __syncthreads(); }
@@ -257,6 +264,115 @@ ACME_DEV void gj_step(double ak, double &dinv, unsigned long long &pivlanes, dou
 #undef ACME_GJ_A
 #undef ACME_GJ_B
 #undef ACME_GJ_HEAD_TEXT
+
+// ---- TWO rows per lane (the mid-size kernel, acme_coop.h: 17 ... 32 unknowns, row p in lane p mod 16, slot p / 16) ----
+// The head of a Gauss-Jordan step whose pivot row sits in lane K of the slot holding `ak` (its entries of the pivot column:
+// ak in the pivot's slot, ao in the other):
+//   piv = row_newbcast:K of ak;  inv = 1 / piv (v_rcp_f64 + the cubic refinement of recip());
+//   ak <- -ak * inv, ao <- -ao * inv           (minus the multipliers, recorded IN PLACE: column K of the factors)
+//   in the pivot's lane: dinv <- inv, ak <- 0, frz <- vmxk      (what gj_step does for one row per lane)
+//   vmxk / vmxo: the largest |multiplier| each row has seen (frz: as a row still waiting to be the pivot)
+// Always with the two DPP wait states in front: ak was written by the first update of the step before.
+#define ACME_GJ2_HEAD_TEXT                                                                          \
+        "s_nop 1\n\t"                                                                               \
+        "v_mov_b64_dpp %[piv], %[ak] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"              \
+        "v_rcp_f64_e32 %[inv], %[piv]\n\t"                                                           \
+        "s_nop 0\n\t"                                                                               \
+        "v_fma_f64 %[e], -%[piv], %[inv], 1.0\n\t"                                                   \
+        "v_fmac_f64_e32 %[e], %[e], %[e]\n\t"                                                        \
+        "v_fmac_f64_e32 %[inv], %[inv], %[e]\n\t"                                                    \
+        "v_mul_f64 %[ak], %[ak], -%[inv]\n\t"                                                        \
+        "v_mul_f64 %[ao], %[ao], -%[inv]\n\t"                                                        \
+        "s_and_saveexec_b64 %[sv], %[m]\n\t"                                                         \
+        "v_mov_b64 %[dinv], %[inv]\n\t"                                                              \
+        "v_mov_b64 %[ak], 0\n\t"                                                                     \
+        "v_mov_b64 %[frz], %[vmxk]\n\t"                                                              \
+        "s_mov_b64 exec, %[sv]\n\t"                                                                  \
+        "v_max_f64 %[vmxk], %[vmxk], |%[ak]|\n\t"                                                    \
+        "v_max_f64 %[vmxo], %[vmxo], |%[ao]|\n\t"
+template <int K> ACME_DEV void gj2_head(double &ak, double &ao, double &dinv, double &vmxk, double &vmxo, double &frz) {
+    double piv, inv, e;
+    unsigned long long sv;
+    // (the lane mask materialised HERE, as lanes_here() does: hoisted, the 2 x 32 constants of an elimination are spilled)
+    unsigned half;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(half) : "n"((1u << K) * 0x10001u));
+    const unsigned long long m = ((unsigned long long)half << 32) | half;
+    asm volatile(ACME_GJ2_HEAD_TEXT
+                 : [piv] "=&v"(piv), [inv] "=&v"(inv), [e] "=&v"(e), [ak] "+v"(ak), [ao] "+v"(ao), [dinv] "+v"(dinv),
+                   [sv] "=&s"(sv), [vmxk] "+v"(vmxk), [vmxo] "+v"(vmxo), [frz] "+v"(frz)
+                 : [m] "s"(m), [k] "n"(K) : "scc");
+}
+#undef ACME_GJ2_HEAD_TEXT
+// ... and its row updates, column by column: first the other slot's row  ro += (lane K of rk's row) * nlo,  then the pivot
+// slot's own  rk += (lane K of rk's row) * nlk  (nlk is 0 in the pivot's lane: the pivot row stays).  rk is read through
+// DPP before the step writes it, and was last written a whole step ago -- by the program; the register allocator may still
+// reload it (v_accvgpr_read: the instantiations live beyond 256 registers) right in front of a statement, so each begins
+// with the two wait states (tools/dpp_hazard_check.py found exactly that).  Six columns to a statement (operand limit).
+#define ACME_G2S(j) "v_fmac_f64_dpp %[o" #j "], %[p" #j "], %[nlo] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t" \
+                    "v_fmac_f64_dpp %[p" #j "], %[p" #j "], %[nlk] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define ACME_G2R(j) [o##j] "+v"(*op[O + j]), [p##j] "+v"(*kp[O + j])
+#define ACME_G2S_1 ACME_G2S(0)
+#define ACME_G2R_1 ACME_G2R(0)
+#define ACME_G2S_2 ACME_G2S_1 ACME_G2S(1)
+#define ACME_G2R_2 ACME_G2R_1, ACME_G2R(1)
+#define ACME_G2S_3 ACME_G2S_2 ACME_G2S(2)
+#define ACME_G2R_3 ACME_G2R_2, ACME_G2R(2)
+#define ACME_G2S_4 ACME_G2S_3 ACME_G2S(3)
+#define ACME_G2R_4 ACME_G2R_3, ACME_G2R(3)
+#define ACME_G2S_5 ACME_G2S_4 ACME_G2S(4)
+#define ACME_G2R_5 ACME_G2R_4, ACME_G2R(4)
+#define ACME_G2S_6 ACME_G2S_5 ACME_G2S(5)
+#define ACME_G2R_6 ACME_G2R_5, ACME_G2R(5)
+#define ACME_G2_CASE(n) \
+    if constexpr (CNT == n) asm volatile("s_nop 1\n\t" ACME_G2S_##n : ACME_G2R_##n : [nlk] "v"(nlk), [nlo] "v"(nlo), [k] "n"(K));
+template <int K, int O, int CNT, int M> ACME_DEV void gj2_update_seg(double nlk, double nlo, double *const (&kp)[M], double *const (&op)[M]) {
+    static_assert(CNT >= 1 && CNT <= 6 && O + CNT <= M, "");
+    ACME_G2_CASE(1) ACME_G2_CASE(2) ACME_G2_CASE(3) ACME_G2_CASE(4) ACME_G2_CASE(5) ACME_G2_CASE(6)
+}
+template <int K, int O, int M> ACME_DEV void gj2_update_from(double nlk, double nlo, double *const (&kp)[M], double *const (&op)[M]) {
+    if constexpr (O < M) {
+        constexpr int CNT = M - O < 6 ? M - O : 6;
+        gj2_update_seg<K, O, CNT>(nlk, nlo, kp, op);
+        gj2_update_from<K, O + CNT>(nlk, nlo, kp, op);
+    }
+}
+// M columns: kp[j] the pivot slot's register of column j, op[j] the other slot's
+template <int K, int M> ACME_DEV void gj2_update(double nlk, double nlo, double *const (&kp)[M], double *const (&op)[M]) {
+    gj2_update_from<K, 0>(nlk, nlo, kp, op);
+}
+#undef ACME_G2_CASE
+// The REPLAY of such an elimination on another right-hand side (xk: the entries of the rows in the pivot's slot, xo: the
+// other slot's; mk[j] / mo[j]: the recorded multipliers of step K0 + j): every step reads through DPP what the step before
+// wrote -- two wait states each.  Eight steps to a statement.
+#define ACME_R2S(j) "s_nop 1\n\t" \
+                    "v_fmac_f64_dpp %[xo], %[xk], %[mo" #j "] row_newbcast:%[k" #j "] row_mask:0xf bank_mask:0xf\n\t" \
+                    "v_fmac_f64_dpp %[xk], %[xk], %[mk" #j "] row_newbcast:%[k" #j "] row_mask:0xf bank_mask:0xf\n\t"
+#define ACME_R2I(j) [mo##j] "v"(mo[C0 + j]), [mk##j] "v"(mk[C0 + j]), [k##j] "n"((K0 + j) % 16)
+#define ACME_R2S_1 ACME_R2S(0)
+#define ACME_R2I_1 ACME_R2I(0)
+#define ACME_R2S_2 ACME_R2S_1 ACME_R2S(1)
+#define ACME_R2I_2 ACME_R2I_1, ACME_R2I(1)
+#define ACME_R2S_3 ACME_R2S_2 ACME_R2S(2)
+#define ACME_R2I_3 ACME_R2I_2, ACME_R2I(2)
+#define ACME_R2S_4 ACME_R2S_3 ACME_R2S(3)
+#define ACME_R2I_4 ACME_R2I_3, ACME_R2I(3)
+#define ACME_R2S_5 ACME_R2S_4 ACME_R2S(4)
+#define ACME_R2I_5 ACME_R2I_4, ACME_R2I(4)
+#define ACME_R2S_6 ACME_R2S_5 ACME_R2S(5)
+#define ACME_R2I_6 ACME_R2I_5, ACME_R2I(5)
+#define ACME_R2S_7 ACME_R2S_6 ACME_R2S(6)
+#define ACME_R2I_7 ACME_R2I_6, ACME_R2I(6)
+#define ACME_R2S_8 ACME_R2S_7 ACME_R2S(7)
+#define ACME_R2I_8 ACME_R2I_7, ACME_R2I(7)
+#define ACME_R2_CASE(n) \
+    if constexpr (CNT == n) asm volatile(ACME_R2S_##n : [xk] "+v"(xk), [xo] "+v"(xo) : ACME_R2I_##n);
+// steps K0 .. K0 + CNT - 1 (all with their pivot in the SAME slot: K0 / 16 == (K0 + CNT - 1) / 16), multipliers at
+// mk / mo [C0 ...]
+template <int K0, int CNT, int C0, int M> ACME_DEV void replay2_seg(double &xk, double &xo, const double (&mk)[M], const double (&mo)[M]) {
+    static_assert(CNT >= 1 && CNT <= 8 && C0 + CNT <= M && K0 / 16 == (K0 + CNT - 1) / 16, "");
+    ACME_R2_CASE(1) ACME_R2_CASE(2) ACME_R2_CASE(3) ACME_R2_CASE(4) ACME_R2_CASE(5) ACME_R2_CASE(6) ACME_R2_CASE(7) ACME_R2_CASE(8)
+}
+#undef ACME_R2_CASE
 
 // bcast16<K> as a volatile statement (ordered with the fused operations); SAFE: with the two wait
 // states built in

@@ -160,6 +160,7 @@ void run_block(int bid, void (*entry)(void *), void *arg);
 }  // namespace emu
 
 namespace wv {
+ACME_DEV constexpr bool lockstep() { return false; }
 ACME_DEV int tid() { return emu::g_blk->fibers[emu::g_blk->cur].tid; }
 ACME_DEV int bid() { return emu::g_blk->bid; }
 ACME_DEV void block_sync() { emu::block_sync(); }
@@ -208,6 +209,32 @@ template <int K, int CNT, bool SAFE>
 ACME_DEV void gj_step(double ak, double &dinv, unsigned long long &pivlanes, double &nlm, double &vmx, double &frz, double *const (&rp)[CNT]) {
     gj_step_head<K, SAFE>(ak, dinv, pivlanes, nlm, vmx, frz);
     for (int j = 0; j < CNT; ++j) *rp[j] = fma(bcast16<K>(*rp[j]), nlm, *rp[j]);
+}
+// two rows per lane (acme_coop.h): step head, row updates and replay of the Gauss-Jordan elimination -- the operations of
+// the asm statements in acme_wave_hip.h, one by one (recip() here is the correctly rounded 1 / x)
+template <int K> ACME_DEV void gj2_head(double &ak, double &ao, double &dinv, double &vmxk, double &vmxo, double &frz) {
+    const double piv = bcast16<K>(ak);
+    const double inv = recip(piv);
+    ak = ak * -inv;
+    ao = ao * -inv;
+    if (lanes((1ull << K) * 0x0001000100010001ull)) { dinv = inv; ak = 0.0; frz = vmxk; }
+    vmxk = fmax(vmxk, fabs(ak));
+    vmxo = fmax(vmxo, fabs(ao));
+}
+template <int K, int M> ACME_DEV void gj2_update(double nlk, double nlo, double *const (&kp)[M], double *const (&op)[M]) {
+    for (int j = 0; j < M; ++j) {
+        const double b = bcast16<K>(*kp[j]);
+        *op[j] = fma(b, nlo, *op[j]);
+        *kp[j] = fma(b, nlk, *kp[j]);
+    }
+}
+template <int K0, int CNT, int C0, int M> ACME_DEV void replay2_seg(double &xk, double &xo, const double (&mk)[M], const double (&mo)[M]) {
+    if constexpr (CNT > 0) {
+        const double b = bcast16<K0 % 16>(xk);
+        xo = fma(b, mo[C0], xo);
+        xk = fma(b, mk[C0], xk);
+        replay2_seg<K0 + 1, CNT - 1, C0 + 1>(xk, xo, mk, mo);
+    }
 }
 template <int R> ACME_DEV double ror16(double v) {
     int lane = tid() & 63;

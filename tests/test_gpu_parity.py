@@ -23,7 +23,7 @@ def runner(hip_lib, model, n, **kw):
     ("superover_fixed", 20, 1024, RTOL_SAME),    # 4.6e-14
     ("superover_var", 33, 1024, RTOL_SAME),      # 8.7e-15
     ("birdie_fixed", 16, 2048, RTOL_SAME),       # 1.8e-14
-    ("birdie_var", 18, 2048, RTOL),              # 1.9e-9: one homotopy episode takes another path
+    ("birdie_var", 18, 2048, RTOL),              # 1.9e-9: homotopy episodes take other paths (test_birdie_var_iteration_gap_is_rounding)
     ("birdie_var_176k", 16, 4096, 1e-9),         # 5.7e-11; BASELINE config 5's model (fs = 176.4 kHz, variable vol)
     ("rc_ladder", 5, 512, 1e-14),                # 8.3e-17 (linear)
     ("sallenkey", 4, 512, 1e-14),                # 3.3e-16 (linear)
@@ -40,6 +40,44 @@ def test_sweep_matches_oracle(hip_lib, name, N, T, rtol):
     assert (ra["first_nonfinite"] < 0).all()
     if rtol == RTOL_SAME:
         assert abs(int(ra["iters_total"].sum()) - int(its.sum())) <= 1e-3 * its.sum()
+
+
+def test_birdie_var_iteration_gap_is_rounding(hip_lib, monkeypatch):
+    """The one sweep above held to RTOL: why the kernels need 8 % more iterations than the oracle there (tests/birdie_gap.py has
+    the story; tests/test_emu_parity.py the same test on the emulated kernels, with the oracle's own sensitivity).  On the GPU:
+    the 16-lane kernel AND the lane-per-instance generic kernel (the reference's LU, literally) both part from the oracle in
+    instances 14 ... 17 only, each its own way; at (instance 17, sample 2) the reference's direct attempt overflows after 3
+    iterations and the homotopy takes over, the kernel's converges by itself, and both solves end at the same z."""
+    import birdie_gap as bg
+    m = load(bg.NAME)
+    u = sweep_inputs(bg.NAME, bg.N, bg.T)
+    yref, its = oracle_run(m, u)
+
+    def make(n, model=None):
+        return runner(hip_lib, model or m, n)
+
+    totals = {}
+    for kernel in ("16-lane", "lane per instance, literal LU"):
+        if kernel != "16-lane":
+            monkeypatch.setenv("ACME_GENERIC", "1")
+        r = make(bg.N)
+        y = r.run(u)
+        assert_close(y, yref)
+        totals[kernel] = r.report_arrays()["iters_total"]
+        monkeypatch.delenv("ACME_GENERIC", raising=False)
+        d = totals[kernel] - its
+        assert (d[:14] == 0).all() and (d[14:] != 0).all(), (kernel, d.tolist())
+    print("birdie_var iteration totals: oracle", int(its.sum()), {k: int(v.sum()) for k, v in totals.items()})
+    for inst in (14, 17):
+        io, ik = bg.per_sample_iterations(make, m, u[inst], bg.PARTING[inst] + 1)
+        assert (io != ik).any() and int(np.argmax(io != ik)) == bg.PARTING[inst], (inst, io.tolist(), ik.tolist())
+    _, out = bg.direct_attempts(make, m, u[17], 2)
+    (oc, oi), (kc, ki), _ = out["SimpleSolver"]
+    assert not oc and oi == 3 and kc and ki > 5 * oi, out
+    (oc, oi), (kc, ki), dz = out["HomotopySolver{SimpleSolver}"]
+    assert oc and kc and dz < 1e-10, out
+    print("direct attempt at (17, 2): oracle", out["SimpleSolver"][0], "kernel", out["SimpleSolver"][1],
+          "| full solve: oracle", out["HomotopySolver{SimpleSolver}"][0], "kernel", out["HomotopySolver{SimpleSolver}"][1])
 
 
 def test_config1_doctest_golden(hip_lib):
@@ -836,14 +874,22 @@ def test_host_arrays_may_be_freed_after_any_call(hip_lib):
 
 
 def test_mid_size_kernel(hip_lib, monkeypatch):
-    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 18 / 27 / 34 / 20 unknowns (what the reference's LU "for sizes up to about
-    60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full waves and a ragged
-    last one): the oracle's outputs (RTOL_SAME) and iteration totals, and the lane-per-instance kernel's.  17 ... 32
-    unknowns run the instantiation with the running factorisation in registers; the any-size one (everything in LDS,
-    ACME_COOP_REG=0) gives the same bits and the same iteration counts, and so does either in any launch shape."""
+    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 18 / 27 / 22 (ties) / 34 / 20 unknowns (what the reference's LU
+    "for sizes up to about 60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full
+    waves and a ragged last one): the oracle's outputs (RTOL_SAME) and iteration totals.
+    17 ... 32 unknowns run the THRESHOLD path by default (elimination in a learnt row order, |l| <= 8: the a-13 deviation the
+    tuned kernels make) -- held to the oracle at RTOL_SAME with the oracle's iteration totals, to the same bits in every
+    launch shape, for a lone instance, a ragged block and private images.  ACME_COOP_LITERAL=1 selects the reference's
+    pivoting literally: every instantiation of it (factorisation in registers, everything in LDS = what 33 ... 64 unknowns
+    use) in every launch shape gives the same bits as every other and agrees with the lane-per-instance kernel entry by entry."""
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
+    pins = ("ACME_COOP_REG", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL")
+
+    def split_run(r, u):
+        return np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+
     for name, m, u5 in mid_size_models(more=True) + beyond_the_tuned_shapes()[:1]:
         N, T = 70, u5.shape[2]
         u = np.logspace(-1.5, 0.6, N)[:, None, None] * u5[2:3] / np.abs(u5[2]).max()
@@ -852,42 +898,59 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             yref, its = oracle_run(m, u, cache_limit=lim)
             r = ModelRunner(m, N, lib=hip_lib)
             assert r.kernel_family() == "coop"
-            y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+            y = split_run(r, u)
             err = assert_close(y, yref, rtol=RTOL_SAME)
             assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
             # a lone instance (one group of one wave of a four-wave block) and 17 (a ragged second block): the same bits
-            for few in (1, 17):
+            for few in (1, 2, 3, 17):
                 rf = ModelRunner(m, few, lib=hip_lib)
-                yf = np.concatenate([rf.run(u[:few, :, :50]), rf.run(u[:few, :, 50:])], axis=2)
-                assert np.array_equal(y[:few], yf), (name, solver, few)
+                assert np.array_equal(y[:few], split_run(rf, u[:few])), (name, solver, few)
             # a batch of private model images (acme_batch_set_matrices: the image then stays in L2): the same bits
             rp = ModelRunner(m, N, lib=hip_lib, models=[m] * N)
             assert rp.kernel_family() == "coop"
-            yp = np.concatenate([rp.run(u[:, :, :50]), rp.run(u[:, :, 50:])], axis=2)
-            assert np.array_equal(y, yp), (name, solver, "private images")
-            # every instantiation in every launch shape (waves per block sharing the staged tables / image, instances per
-            # wave, image in LDS or in L2 -- by default whatever keeps most instances resident, csrc/acme_api.inc
-            # coop_shape; a pinned shape that does not fit is ignored): the same bits
-            pins = ("ACME_COOP_REG", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL")
+            assert np.array_equal(y, split_run(rp, u)), (name, solver, "private images")
+            # the default path in every launch shape (waves per block sharing the staged tables / image, instances per wave
+            # -- 1, 2 and 4: ADVICE r5 --, image in LDS or in L2; by default whatever keeps most instances resident,
+            # csrc/acme_api.inc coop_shape; a pinned shape that does not fit is ignored): the same bits
+            for shape in ("110", "120", "140", "241", "321", "441", "420", "411"):
+                for k, v in zip(pins, ("1",) + tuple(shape)):
+                    monkeypatch.setenv(k, v)
+                rl = ModelRunner(m, N, lib=hip_lib)
+                assert rl.kernel_family() == "coop"
+                yl = split_run(rl, u)
+                assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, shape)
+                assert np.array_equal(y, yl), (name, solver, "default path", shape)
+            for k in pins:
+                monkeypatch.delenv(k)
+            # the reference's pivoting literally: every instantiation in every launch shape, the same bits
+            monkeypatch.setenv("ACME_COOP_LITERAL", "1")
+            ylit = None
             for reg in ("1", "0"):
-                for shape in ("110", "120", "140", "241", "321", "441", "420", "411"):
+                for shape in ("", "110", "120", "140", "241", "321", "441", "420", "411"):
                     for k, v in zip(pins, (reg,) + tuple(shape)):
                         monkeypatch.setenv(k, v)
                     rl = ModelRunner(m, N, lib=hip_lib)
                     assert rl.kernel_family() == "coop"
-                    yl = np.concatenate([rl.run(u[:, :, :50]), rl.run(u[:, :, 50:])], axis=2)
+                    yl = split_run(rl, u)
                     assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, reg, shape)
-                    assert np.array_equal(y, yl), (name, solver, "registers" if reg == "1" else "LDS", shape)
-            for k in pins:
-                monkeypatch.delenv(k)
+                    if ylit is None:
+                        ylit = yl
+                        assert_close(ylit, yref, rtol=RTOL_SAME)
+                    assert np.array_equal(ylit, yl), (name, solver, "registers" if reg == "1" else "LDS", shape)
+                    for k in pins:
+                        monkeypatch.delenv(k, raising=False)
+            monkeypatch.delenv("ACME_COOP_LITERAL")
             monkeypatch.setenv("ACME_COOP", "0")
             r0 = ModelRunner(m, N, lib=hip_lib)
             assert r0.kernel_family() == "generic"
-            y0 = np.concatenate([r0.run(u[:, :, :50]), r0.run(u[:, :, 50:])], axis=2)
+            y0 = split_run(r0, u)
             monkeypatch.delenv("ACME_COOP")
-            print(f"mid-size kernel, {name}, {solver}: rel err vs oracle {err:.2e}, vs the lane-per-instance kernel "
-                  f"{np.abs(y - y0).max():.2e}, iterations {int(its.sum())} = oracle's")
-            assert np.abs(y - y0).max() <= 1e-13 * max(1.0, np.abs(yref).max())
+            scale = max(1.0, np.abs(yref).max())
+            print(f"mid-size kernel, {name}, {solver}: rel err vs oracle {err:.2e}, literal path vs the lane-per-instance kernel "
+                  f"{np.abs(ylit - y0).max():.2e}, default path vs literal {np.abs(y - ylit).max() / scale:.2e}, "
+                  f"iterations {int(its.sum())} = oracle's")
+            assert np.abs(ylit - y0).max() <= 1e-13 * scale
+            assert np.abs(y - ylit).max() <= RTOL_SAME * scale
 
 
 def test_streamed_host_path_only_when_the_grid_is_resident(hip_lib):
