@@ -13,13 +13,16 @@
 //   HomotopySolver  src/solvers.jl:247-302   CachingSolver  src/solvers.jl:319-396 (bounded store, as everywhere here)
 // so outputs and iteration counts are the generic kernel's (and the oracle's) -- only WHO computes an entry differs.
 // Two instantiations (GArgs::coop_nc):
-//   * any size (33 ... 64 unknowns): every working array of an instance in LDS at the generic kernel's offsets; the
-//     elimination walks through LDS, row interchanges are real and kept as the composed gather src[]
-//     (x_permuted[i] = x[src[i]]), which is what solve! applies first (src/solvers.jl:103-109);
-//   * 17 ... 32 unknowns (one kernel per column count, rounded up to four): the running factorisation lives in REGISTERS
-//     from evaluate! to the Newton step, rows never move (a position label stands for the interchanges), only an accepted
-//     iterate's factors go to LDS -- 8.8 KB per instance at 20 unknowns, 16 instances per compute unit: see below
-//     ("the running factorisation in REGISTERS").
+//   * any size (33 ... 64 unknowns; ACME_COOP_LITERAL=1: every size): every working array of an instance in LDS at the generic
+//     kernel's offsets; the elimination walks through LDS, row interchanges are real and kept as the composed gather src[]
+//     (x_permuted[i] = x[src[i]]), which is what solve! applies first (src/solvers.jl:103-109) -- the reference's arithmetic
+//     entry by entry, outputs bit-identical to the lane-per-instance kernel's;
+//   * 17 ... 32 unknowns (one kernel per column count, rounded up to four): the Jacobian's rows live in REGISTERS from
+//     evaluate! to the Newton step, two per lane, and are eliminated the way the tuned 16-lane kernels do it -- in the row
+//     order the instance has learnt, without a pivot search while every multiplier stays below a threshold, Gauss-Jordan
+//     with fused DPP multiply-adds, the Newton step riding along: see below ("the THRESHOLD path").  The reference's
+//     pivoting (coop_lu_rows) runs only to LEARN a new order.  Results agree with the reference's to rounding (the stated
+//     deviation a-13 of DESIGN.md), iteration totals are the oracle's on every parity case.
 // The waves of a block share one staged copy of the row tables and, if the batch shares its model image, of the image
 // (GArgs::coop_wpb / coop_gpw / coop_imgl: the launch shape, chosen per model by the host, acme_api.inc coop_shape).
 //
@@ -423,8 +426,8 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
 constexpr int COOP_REG_SLOTS = 2;
 
 // evaluate!(nleq, z) as coop_evaluate, the rows' residuals, Jacobian rows (columns >= nn: zero) and Jq non-zeros in registers.
-// rid: WHICH row of the sub-problem each slot of the lane evaluates (-1: none) -- slot sl's own row lig + 16 sl on the
-// literal path, the row the instance's learnt order puts at that position on the threshold path (coop_gj_rows)
+// rid: WHICH row of the sub-problem each slot of the lane evaluates (-1: none) -- the row the instance's learnt order puts
+// at the slot's position (coop_gj_rows)
 template <int NC>
 ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, double (&a)[COOP_REG_SLOTS][NC],
                                  double (&res)[COOP_REG_SLOTS], double (&tvr)[COOP_REG_SLOTS][4], const int (&rid)[COOP_REG_SLOTS]) {
@@ -477,8 +480,8 @@ ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, dou
 }
 
 // calc_Jp closure with the Jq non-zeros of the latest coop_evaluate_rows (of the rows rid), written to the origin's Jp where
-// `pred` -- row rid[sl] of Jp at row wrow[sl] of the stored matrix (the literal path: the row's own number; the threshold
-// path: the position the row holds, which is where the replayed elimination expects its right-hand side)
+// `pred` -- row rid[sl] of Jp at row wrow[sl] of the stored matrix: the position the row holds, which is where the replayed
+// elimination expects its right-hand side
 ACME_DEV void coop_calc_jp_rows(const CoopCtx &c, const GenSub &s, const double (&tvr)[COOP_REG_SLOTS][4], bool pred,
                                 const int (&rid)[COOP_REG_SLOTS], const int (&wrow)[COOP_REG_SLOTS]) {
     sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
@@ -618,129 +621,7 @@ ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][
     return ok;
 }
 
-// solve! with the factors as coop_lu_rows left them (rows in their lanes, positions in pos).  xs: in, the right-hand side
-// of the lane's rows (x_permuted[pos] = x[row]: the gather is the layout); out, the solution's entry number pos of each row.
-// A sweep's x_j comes from whichever lane holds position j: it writes it to LDS, everyone reads it.
-template <int NC>
-ACME_DEV void coop_solve_rows(const CoopCtx &c, int n, const double (&a)[COOP_REG_SLOTS][NC], const int (&pos)[COOP_REG_SLOTS],
-                              double (&xs)[COOP_REG_SLOTS]) {
-    constexpr int NS = COOP_REG_SLOTS;
-    double *X = c.W + c.O.xb;
-    bool real[NS];
-    sfor<0, NS>([&](auto sc) ACME_LAMBDA { real[decltype(sc)::value] = c.lig + GROUP * decltype(sc)::value < n; });
-    // forward: x_i -= F[i][j] x_j for i > j
-    sfor<0, NC>([&](auto jc) ACME_LAMBDA {
-        constexpr int j = decltype(jc)::value;
-        if (j < n) {
-            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                if (real[sl] && pos[sl] == j) X[j] = xs[sl];
-            });
-            wv::lds_order();
-            const double xj = X[j];
-            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                const double t = xs[sl] - a[sl][j] * xj;
-                xs[sl] = (real[sl] && pos[sl] > j) ? t : xs[sl];
-            });
-        }
-    });
-    // backward: x_j *= 1 / F[j][j] (stored), x_i -= F[i][j] x_j for i < j
-    sfor_down<NC>([&](auto jc) ACME_LAMBDA {
-        constexpr int j = decltype(jc)::value;
-        if (j < n) {
-            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                if (real[sl] && pos[sl] == j) X[j] = a[sl][j] * xs[sl];
-            });
-            wv::lds_order();
-            const double xj = X[j];
-            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                const double t = xs[sl] - a[sl][j] * xj;
-                xs[sl] = pos[sl] == j ? xj : ((real[sl] && pos[sl] < j) ? t : xs[sl]);
-            });
-        }
-    });
-}
-
-// an accepted iterate's factors into the origin's matrix in LDS, every row at its position, with the gather solve! starts
-// from (src[position] = row) -- what coop_lu leaves behind, for the instances with `pred`
-template <int NC>
-ACME_DEV void coop_store_factors(const CoopCtx &c, int n, const double (&a)[COOP_REG_SLOTS][NC], const int (&pos)[COOP_REG_SLOTS], bool pred) {
-    double *F = c.W + c.O.llu;
-    sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
-        constexpr int sl = decltype(sc)::value;
-        const int i = c.lig + GROUP * sl;
-        if (pred && i < n) {
-            sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
-                constexpr int g = decltype(gc)::value;
-                wv::st2(F + pos[sl] * c.O.ld + 2 * g, a[sl][2 * g], a[sl][2 * g + 1]);
-            });
-            c.W[c.O.lsrc + pos[sl]] = (double)i;
-        }
-    });
-    wv::wave_fence();
-}
-
-// solve! with a lane's rows of the factors in registers (read once, ds_read_b128) and x_j handed round by DPP broadcasts
-// (row j of the final order sits in lane j mod 16: a compile-time lane): the 2 n sequential steps cost a broadcast and a
-// multiply-add each, where coop_lu_solve's cost an LDS read and a ds_bpermute round trip.  Same arithmetic, same order.
-template <int NC> ACME_DEV void coop_lu_solve_reg(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
-    constexpr int NS = COOP_REG_SLOTS;
-    double *W = c.W;
-    const int ld = c.O.ld;
-    const double *F = W + o_f;
-    double f[NS][NC], xs[NS];
-    bool real[NS];
-    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-        constexpr int sl = decltype(sc)::value;
-        const int i = c.lig + GROUP * sl;
-        real[sl] = i < n;
-        xs[sl] = real[sl] ? W[w_x + (int)W[o_src + i]] : 0.0;
-        sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
-            constexpr int g = decltype(gc)::value;
-            wv::pair_t v{0.0, 0.0};
-            if (real[sl]) v = wv::ld2(F + i * ld + 2 * g);
-            f[sl][2 * g] = v.lo;
-            f[sl][2 * g + 1] = v.hi;
-        });
-    });
-    // forward: x_i -= F[i][j] x_j for i > j
-    sfor<0, NC>([&](auto jc) ACME_LAMBDA {
-        constexpr int j = decltype(jc)::value;
-        if (j < n) {
-            const double xj = wv::bcast16<j % GROUP>(xs[j / GROUP]);
-            sfor<j / GROUP, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                const int i = c.lig + GROUP * sl;
-                const double t = xs[sl] - f[sl][j] * xj;
-                xs[sl] = (real[sl] && i > j) ? t : xs[sl];
-            });
-        }
-    });
-    // backward: x_j *= 1 / F[j][j] (stored), x_i -= F[i][j] x_j for i < j
-    sfor_down<NC>([&](auto jc) ACME_LAMBDA {
-        constexpr int j = decltype(jc)::value;
-        if (j < n) {
-            const double xj = wv::bcast16<j % GROUP>(f[j / GROUP][j]) * wv::bcast16<j % GROUP>(xs[j / GROUP]);
-            sfor<0, j / GROUP + 1>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                const int i = c.lig + GROUP * sl;
-                const double t = xs[sl] - f[sl][j] * xj;
-                xs[sl] = i == j ? xj : (i < j ? t : xs[sl]);
-            });
-        }
-    });
-    wv::wave_fence();
-    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-        constexpr int sl = decltype(sc)::value;
-        if (real[sl]) W[w_x + c.lig + GROUP * sl] = xs[sl];
-    });
-    wv::wave_fence();
-}
-
-// ---- the THRESHOLD path (THR; 17 ... 32 unknowns): the tuned 16-lane kernels' elimination, two rows per lane ----
+// ---- the THRESHOLD path (17 ... 32 unknowns): the tuned 16-lane kernels' elimination, two rows per lane ----
 // coop_lu_rows above reproduces the reference's dynamic first-strict-maximum pivoting bit for bit, and pays for it at every
 // step: a search (16-lane reduction), the pivot row's round trip through LDS, an IEEE division -- 40 % of the kernel's
 // cycles (profiles/r5_coop_timing.txt).  The tuned kernels (acme_kernel.h RowLU::solve_inplace) do not look for pivots:
@@ -857,9 +738,8 @@ template <int NC> ACME_DEV void coop_replay_gj(const CoopCtx &c, int n, int w_x)
 }
 
 // the extrapolation's solve! of a kernel instantiated for NC columns (0: the LDS version, any size)
-template <int NC, bool THR> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
-    if constexpr (NC > 0 && THR) coop_replay_gj<NC>(c, n, w_x);
-    else if constexpr (NC > 0) coop_lu_solve_reg<NC>(c, n, o_f, o_src, w_x);
+template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
+    if constexpr (NC > 0) coop_replay_gj<NC>(c, n, w_x);
     else coop_lu_solve(c, n, o_f, o_src, w_x);
 }
 
@@ -948,23 +828,14 @@ ACME_DEV void coop_linearize(const CoopCtx &c, const GenSub &s, CoopSolver &f, i
     }
 }
 
-// set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196) at (w_lp, w_lz) for the instances with `pred`
-template <int NC, bool THR> ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
-    static_assert(!(NC > 0 && THR), "the threshold path re-linearises inside coop_simple_solve (`reorig`): one copy of the pass");
+// set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196) at (w_lp, w_lz) for the instances with `pred` (the any-size
+// instantiation; the register instantiations re-linearise inside coop_simple_solve: `reorig`, one copy of the pass)
+ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
     coop_set_p(c, s, c.O.lp);
-    if constexpr (NC > 0) {
-        double a[COOP_REG_SLOTS][NC], res[COOP_REG_SLOTS], tv[COOP_REG_SLOTS][4];
-        int pos[COOP_REG_SLOTS];
-        (void)coop_evaluate_rows<NC>(c, s, c.O.lz, a, res, tv, f.rid);
-        (void)coop_lu_rows<NC>(c, s.nn, a, pos, f.last);
-        coop_calc_jp_rows(c, s, tv, pred, f.rid, f.rid);
-        coop_store_factors<NC>(c, s.nn, a, pos, pred);
-    } else {
-        (void)coop_evaluate(c, s, c.O.lz, f.o_lu);
-        (void)coop_lu(c, s.nn, f.o_lu, f.o_src);
-        coop_calc_jp(c, s, c.O.ljp, pred);
-        coop_accept_factors(f, pred);
-    }
+    (void)coop_evaluate(c, s, c.O.lz, f.o_lu);
+    (void)coop_lu(c, s.nn, f.o_lu, f.o_src);
+    coop_calc_jp(c, s, c.O.ljp, pred);
+    coop_accept_factors(f, pred);
 }
 
 // solve(::SimpleSolver, p) (src/solvers.jl:207-236) for the instances with `need`: p at w_p, z left in w_zz; returns
@@ -973,7 +844,7 @@ template <int NC, bool THR> ACME_DEV void coop_set_origin(const CoopCtx &c, cons
 // instances -- their origin was replaced by a stored solution (coop_cached_solve) or has no recorded elimination yet (launch
 // start).  It is a pass of the SAME loop as the Newton iterations: evaluate!, the elimination and the re-learning exist
 // once in the kernel (what Shape::ONELOOP is to the tuned kernels), not once per caller.
-template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its, bool reorig = false) {
+template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its, bool reorig = false) {
     const GenHeader &H = c.H;
     double *W = c.W;
     const int nn = s.nn, np = s.np;
@@ -984,7 +855,7 @@ template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, co
         COOP_T(c, CT_SETP);
         for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
         wv::wave_fence();
-        coop_backsolve<NC, THR>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
+        coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
         for (int r = c.lig; r < nn; r += GROUP)
             if (need) W[c.O.zz + r] = W[c.O.lz + r] - W[c.O.tmp + r];
         wv::wave_fence();
@@ -993,7 +864,7 @@ template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, co
     bool act = need, conv = false;
     double reslast = 0.0;
     its = 0;
-    if constexpr (NC > 0 && THR) {
+    if constexpr (NC > 0) {
         constexpr int NS = COOP_REG_SLOTS;
         const int wrow[NS] = {c.lig, c.lig + GROUP};
         int stage = wv::ballot(reorig) != 0ull ? 0 : 1;          // 0: re-linearising at the origin; 1: the start is due; 2: Newton
@@ -1044,53 +915,6 @@ template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, co
             conv = conv || accept;
             act = step && its < c.A.maxiter;
         }
-    } else if constexpr (NC > 0) {
-        start();
-        constexpr int NS = COOP_REG_SLOTS;
-        while (wv::ballot(act) != 0ull) {
-            its += act ? 1 : 0;
-            double a[NS][NC], res[NS], tv[NS][4];
-            int pos[NS];
-            const bool bad = coop_evaluate_rows<NC>(c, s, c.O.zz, a, res, tv, f.rid);
-            COOP_T(c, CT_EVAL);
-            const bool finite = !coop_any(c, bad);
-            double rm = 0.0;
-            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                constexpr int sl = decltype(sc)::value;
-                const double v = fabs(res[sl]);
-                if (c.lig + GROUP * sl < nn && v > rm) rm = v;
-            });
-            double resmax = wv::allmax16(rm);
-            if (!finite) resmax = (double)NAN;
-            const bool ok = coop_lu_rows<NC>(c, nn, a, pos, f.last);
-            COOP_T(c, CT_LU);
-            const bool small = resmax < c.A.tol;
-            const bool accept = act && finite && ok && small;
-            const bool step = act && finite && ok && !small;
-            reslast = act ? resmax : reslast;
-            // the Newton step, straight from the registers (skipped when the whole wave is done stepping)
-            if (wv::ballot(step) != 0ull) {
-                coop_solve_rows<NC>(c, nn, a, pos, res);
-                sfor<0, NS>([&](auto sc) ACME_LAMBDA {
-                    constexpr int sl = decltype(sc)::value;
-                    if (step && c.lig + GROUP * sl < nn) W[c.O.zz + pos[sl]] -= res[sl];
-                });
-            }
-            COOP_T(c, CT_SOLVE);
-            // an accepted iterate: its factors, Jp, p and z become the extrapolation origin
-            if (wv::ballot(accept) != 0ull) {
-                coop_calc_jp_rows(c, s, tv, accept, f.rid, f.rid);
-                coop_store_factors<NC>(c, nn, a, pos, accept);
-                for (int j = c.lig; j < np; j += GROUP)
-                    if (accept) W[c.O.lp + j] = W[w_p + j];
-                for (int r = c.lig; r < nn; r += GROUP)
-                    if (accept) W[c.O.lz + r] = W[c.O.zz + r];
-            }
-            wv::wave_fence();
-            COOP_T(c, CT_ACCEPT);
-            conv = conv || accept;
-            act = step && its < c.A.maxiter;
-        }
     } else {
         start();
         while (wv::ballot(act) != 0ull) {
@@ -1114,7 +938,7 @@ template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, co
             // the Newton step (for everyone; only the stepping instances keep it)
             for (int r = c.lig; r < nn; r += GROUP) W[c.O.dz + r] = W[c.O.res + r];
             wv::wave_fence();
-            coop_backsolve<NC, THR>(c, nn, f.o_lu, f.o_src, c.O.dz);
+            coop_backsolve<NC>(c, nn, f.o_lu, f.o_src, c.O.dz);
             for (int r = c.lig; r < nn; r += GROUP)
                 if (step) W[c.O.zz + r] -= W[c.O.dz + r];
             COOP_T(c, CT_SOLVE);
@@ -1138,7 +962,7 @@ template <int NC, bool THR> ACME_DEV bool coop_simple_solve(const CoopCtx &c, co
 }
 
 // solve(::CachingSolver, p) (src/solvers.jl:347-396) with the bounded store (lane e looks at stored solution e)
-template <int NC, bool THR> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
+template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_p, bool need, int &its) {
     double *W = c.W;
     const int nn = s.nn, np = s.np;
     double *cp = c.Cp;                                                                       // LDS (coop_main loads / stores it)
@@ -1170,12 +994,12 @@ template <int NC, bool THR> ACME_DEV bool coop_cached_solve(const CoopCtx &c, co
             for (int r = c.lig; r < nn; r += GROUP)
                 if (hit) W[c.O.lz + r] = cz[e * nn + r];
             wv::wave_fence();
-            if constexpr (NC > 0 && THR) reorig = reorig || hit;          // (a pass of coop_simple_solve's loop)
-            else coop_set_origin<NC, THR>(c, s, f, hit);
+            if constexpr (NC > 0) reorig = reorig || hit;          // (a pass of coop_simple_solve's loop)
+            else coop_set_origin(c, s, f, hit);
         }
     }
     COOP_T(c, CT_LOOKUP);
-    const bool conv = coop_simple_solve<NC, THR>(c, s, f, w_p, need, its, reorig);
+    const bool conv = coop_simple_solve<NC>(c, s, f, w_p, need, its, reorig);
     if (caching) {
         const bool keep = need && conv && its > 5;
         if (wv::ballot(keep) != 0ull) {
@@ -1199,7 +1023,7 @@ template <int NC, bool THR> ACME_DEV bool coop_cached_solve(const CoopCtx &c, co
 // solve(::HomotopySolver, p) (src/solvers.jl:268-296); p at w_p of the header.  ONE loop whose first pass is the direct
 // attempt (at w_p) and whose later passes are the bisection's (at w_pa): one inlined copy of the solver stack in the kernel
 // instead of two (what Shape::ONELOOP is to the tuned kernels: half the code for the instruction cache to hold).
-template <int NC, bool THR> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool need0, int &its_total) {
+template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool need0, int &its_total) {
     const GenHeader &H = c.H;
     double *W = c.W;
     bool conv = false, need = need0, direct = true;
@@ -1208,7 +1032,7 @@ template <int NC, bool THR> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, 
     its_total = 0;
     do {
         int its;
-        const bool cv = coop_cached_solve<NC, THR>(c, s, f, w_src, need, its);
+        const bool cv = coop_cached_solve<NC>(c, s, f, w_src, need, its);
         its_total += need ? its : 0;
         conv = need ? cv : conv;
         if (direct) {
@@ -1250,7 +1074,7 @@ template <int NC, bool THR> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, 
 // wave has its instances' workspaces.  A dependent load from L2 costs a lone wave ~1 us, and evaluate! alone chains five of
 // them: with four waves to a block the image of a 20-unknown model fits beside 16 instances' workspaces.  After the one
 // barrier behind the staging a wave never talks to another.
-template <bool IMGL, int NC, bool THR> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_in_block, int wave_global, int lane) {
+template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_in_block, int wave_global, int lane) {
     const GenHeader &H = *A.H;
     const int lig = lane & (GROUP - 1), grp = lane >> 4;
     const int gpw = A.coop_gpw, wpb = A.coop_wpb;
@@ -1299,13 +1123,13 @@ template <bool IMGL, int NC, bool THR> ACME_DEV void coop_main(const GArgs &A, d
     long long *rep = A.report + i * RW_WORDS;
     const bool has_sub = H.nsub > 0;
     const GenSub &s = H.sub[0];
-    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}, {-1, -1}, NC > 0 && THR};
-    // the rows the lane's two slots hold: their own (literal path), or what the instance's order -- learnt in earlier
-    // launches, GArgs::coop_order -- puts at the slots' positions (threshold path)
+    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}, {-1, -1}, NC > 0};
+    // the rows the lane's two slots hold: what the instance's order -- learnt in earlier launches, GArgs::coop_order -- puts
+    // at the slots' positions
     if constexpr (NC > 0)
         for (int sl = 0; sl < 2; ++sl) {
             const int p = lig + GROUP * sl;
-            f.rid[sl] = (has_sub && p < s.nn) ? (THR ? A.coop_order[i * (2 * GROUP) + p] : p) : -1;
+            f.rid[sl] = (has_sub && p < s.nn) ? A.coop_order[i * (2 * GROUP) + p] : -1;
         }
     const bool caching = has_sub && A.solver == SOLVER_CACHING_HOMOTOPY;
     double *cache_g = A.cache + i * H.cache_total + (has_sub ? s.c_off : 0);
@@ -1319,8 +1143,8 @@ template <bool IMGL, int NC, bool THR> ACME_DEV void coop_main(const GArgs &A, d
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) Cp[k] = cache_g[k];
     }
     wv::wave_fence();
-    if constexpr (!(NC > 0 && THR))
-        if (has_sub) coop_set_origin<NC, THR>(c, s, f, true);
+    if constexpr (NC == 0)
+        if (has_sub) coop_set_origin(c, s, f, true);
     bool dead = rep[RW_FIRST_NONFINITE] >= 0;
     long long it_total = 0, it_max = 0;
     // this sample's inputs sit in LDS (GenHeader::w_u); the next sample's are requested a sample ahead (HBM latency)
@@ -1355,7 +1179,7 @@ template <bool IMGL, int NC, bool THR> ACME_DEV void coop_main(const GArgs &A, d
             wv::wave_fence();
             COOP_T(c, CT_PRE);
             int its;
-            const bool conv = coop_homotopy_solve<NC, THR>(c, s, f, alive, its);
+            const bool conv = coop_homotopy_solve<NC>(c, s, f, alive, its);
             its_sample = alive ? its : 0;
             const bool failed = alive && !conv;
             if (wv::ballot(failed) != 0ull) {            // the policy of step! (src/ACME.jl:688-694)
@@ -1412,7 +1236,7 @@ template <bool IMGL, int NC, bool THR> ACME_DEV void coop_main(const GArgs &A, d
         for (int r = lig; r < s.nn; r += GROUP) st[H.nx + H.npt + s.zoff + r] = W[c.O.lz + r];
         if (caching)
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) cache_g[k] = Cp[k];
-        if constexpr (NC > 0 && THR)          // (a run split over several launches repeats the one-launch arithmetic)
+        if constexpr (NC > 0)          // (a run split over several launches repeats the one-launch arithmetic)
             for (int sl = 0; sl < 2; ++sl)
                 if (lig + GROUP * sl < s.nn) A.coop_order[i * (2 * GROUP) + lig + GROUP * sl] = f.rid[sl];
     }

@@ -73,11 +73,10 @@ struct GArgs {
     int coop_imgl;           // acme_coop.h: the (shared) model image is staged in LDS
     int coop_gpw;            // acme_coop.h: instances per wave (4, 2 or 1: what the LDS of a compute unit holds most of)
     int coop_wpb;            // acme_coop.h: waves per block (4, 2 or 1: they share one copy of the row tables / the image in LDS)
-    int coop_nc;             // acme_coop.h: the kernel instantiated for this many columns of the factor matrix in registers
-                             // (20, 24, 28, 32: 17 ... 32 unknowns rounded up to four); 0: the any-size kernel (factors in LDS)
-    int coop_thr;            // acme_coop.h: 1: elimination in a learnt row order with threshold pivoting (the default where
-                             // the factorisation is in registers); 0: the reference's pivoting, literally
-    int *coop_order;         // [n_inst][32]: threshold path, the row each position of an instance holds (kept between launches)
+    int coop_nc;             // acme_coop.h: the kernel instantiated for this many columns of the Jacobian in registers (20, 24, 28,
+                             // 32: 17 ... 32 unknowns rounded up to four; threshold pivoting in a learnt row order); 0: the any-size
+                             // kernel (the reference's LU, factors in LDS)
+    int *coop_order;         // [n_inst][32]: register instantiations, the row each position of an instance holds (kept between launches)
 };
 
 #ifdef ACME_DEV

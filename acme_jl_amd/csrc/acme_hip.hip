@@ -148,15 +148,14 @@ static inline int event_elapsed(float *ms, event_t a, event_t b) { return (int)h
 static inline int launch_generic(const GArgs &A, stream_t st) {
     return ACME_LAUNCH(acme_generic_kernel, dim3((unsigned)((A.n_inst + 63) / 64)), dim3(64), 0, st, A);
 }
-// the entry point of a launch shape (GArgs::coop_imgl / coop_nc / coop_thr)
+// the entry point of a launch shape (GArgs::coop_imgl / coop_nc)
 static inline const void *coop_fn(const GArgs &A) {
-    const int thr = A.coop_thr != 0 && A.coop_nc > 0;
     switch (A.coop_nc) {
-    case 20: return acme_coop_fn_nc20(A.coop_imgl, thr);
-    case 24: return acme_coop_fn_nc24(A.coop_imgl, thr);
-    case 28: return acme_coop_fn_nc28(A.coop_imgl, thr);
-    case 32: return acme_coop_fn_nc32(A.coop_imgl, thr);
-    default: return A.coop_imgl ? (const void *)acme_coop_kernel<true, 0, false> : (const void *)acme_coop_kernel<false, 0, false>;
+    case 20: return acme_coop_fn_nc20(A.coop_imgl);
+    case 24: return acme_coop_fn_nc24(A.coop_imgl);
+    case 28: return acme_coop_fn_nc28(A.coop_imgl);
+    case 32: return acme_coop_fn_nc32(A.coop_imgl);
+    default: return coop_fns_of<0>(A.coop_imgl);
     }
 }
 // dynamic LDS beyond 64 KB has to be asked for: per entry point and DEVICE (the caller is on the batch's device), at batch

@@ -264,19 +264,13 @@ static void coop_fiber_entry(void *p) {
     double *lds = c->lds;
     const int wg = c->bid * wpb + wave, lane = tid & 63;
     const bool img = c->A->coop_imgl != 0;
-    const bool thr = c->A->coop_thr != 0;
-#define ACME_COOP_CASE(NC)                                                                                     \
-    if (img) thr ? coop_main<true, NC, true>(*c->A, lds, wave, wg, lane) : coop_main<true, NC, false>(*c->A, lds, wave, wg, lane); \
-    else thr ? coop_main<false, NC, true>(*c->A, lds, wave, wg, lane) : coop_main<false, NC, false>(*c->A, lds, wave, wg, lane);   \
-    break;
     switch (c->A->coop_nc) {
-    case 20: ACME_COOP_CASE(20)
-    case 24: ACME_COOP_CASE(24)
-    case 28: ACME_COOP_CASE(28)
-    case 32: ACME_COOP_CASE(32)
-    default: img ? coop_main<true, 0, false>(*c->A, lds, wave, wg, lane) : coop_main<false, 0, false>(*c->A, lds, wave, wg, lane); break;
+    case 20: img ? coop_main<true, 20>(*c->A, lds, wave, wg, lane) : coop_main<false, 20>(*c->A, lds, wave, wg, lane); break;
+    case 24: img ? coop_main<true, 24>(*c->A, lds, wave, wg, lane) : coop_main<false, 24>(*c->A, lds, wave, wg, lane); break;
+    case 28: img ? coop_main<true, 28>(*c->A, lds, wave, wg, lane) : coop_main<false, 28>(*c->A, lds, wave, wg, lane); break;
+    case 32: img ? coop_main<true, 32>(*c->A, lds, wave, wg, lane) : coop_main<false, 32>(*c->A, lds, wave, wg, lane); break;
+    default: img ? coop_main<true, 0>(*c->A, lds, wave, wg, lane) : coop_main<false, 0>(*c->A, lds, wave, wg, lane); break;
     }
-#undef ACME_COOP_CASE
 }
 static inline int coop_prepare(const GArgs &, size_t) { return 0; }
 static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t) {

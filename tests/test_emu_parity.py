@@ -881,18 +881,14 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
             m.solver = solver
             yref, its = oracle_run(m, u, cache_limit=lim)
             outs = {}
-            for variant in ("coop", "coop, private images", "coop, literal", "coop, literal, factors in LDS", "lane per instance"):
+            for variant in ("coop", "coop, private images", "coop, literal", "lane per instance"):
                 if variant == "lane per instance":
                     monkeypatch.setenv("ACME_COOP", "0")
                 else:
                     monkeypatch.delenv("ACME_COOP", raising=False)
-                # (17 ... 32 unknowns run the instantiation with the factor matrix's rows in registers -- by default on the
-                # threshold path (learnt row order, |l| <= 8), with ACME_COOP_LITERAL=1 with the reference's pivoting;
-                # ACME_COOP_REG=0 selects the any-size one with the factors in LDS, which 33 ... 64 unknowns use)
-                if "LDS" in variant:
-                    monkeypatch.setenv("ACME_COOP_REG", "0")
-                else:
-                    monkeypatch.delenv("ACME_COOP_REG", raising=False)
+                # (17 ... 32 unknowns run the instantiations with the Jacobian's rows in registers: elimination in a learnt
+                # row order, |l| <= 8; ACME_COOP_LITERAL=1 selects the any-size instantiation -- the reference's pivoting,
+                # factors in LDS --, which 33 ... 64 unknowns always use)
                 if "literal" in variant:
                     monkeypatch.setenv("ACME_COOP_LITERAL", "1")
                 else:
@@ -906,19 +902,18 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
                 outs[variant] = y
             monkeypatch.delenv("ACME_COOP", raising=False)
             assert np.array_equal(outs["coop"], outs["coop, private images"]), name
-            assert np.array_equal(outs["coop, literal"], outs["coop, literal, factors in LDS"]), name
             # the launch shape (waves per block sharing the staged tables / image, instances per wave, image in LDS or
             # not: csrc/acme_api.inc coop_shape) does not show in the bits
             if solver is HS:
-                for lit, reg, wpb, gpw, imgl in (("0", "1", "4", "4", "1"), ("0", "1", "3", "2", "0"), ("0", "1", "1", "1", "1"),
-                                                 ("1", "1", "3", "2", "0"), ("1", "0", "2", "1", "1"), ("1", "0", "1", "4", "0")):
-                    for k, v in (("ACME_COOP_LITERAL", lit), ("ACME_COOP_REG", reg), ("ACME_COOP_WPB", wpb), ("ACME_COOP_GPW", gpw), ("ACME_COOP_IMGL", imgl)):
+                for lit, wpb, gpw, imgl in (("0", "4", "4", "1"), ("0", "3", "2", "0"), ("0", "1", "1", "1"),
+                                            ("1", "3", "2", "0"), ("1", "2", "1", "1"), ("1", "1", "4", "0")):
+                    for k, v in (("ACME_COOP_LITERAL", lit), ("ACME_COOP_WPB", wpb), ("ACME_COOP_GPW", gpw), ("ACME_COOP_IMGL", imgl)):
                         monkeypatch.setenv(k, v)
                     r = ModelRunner(m, u.shape[0], lib=emu_lib)
                     y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
-                    assert np.array_equal(y, outs["coop, literal" if lit == "1" else "coop"]), (name, lit, reg, wpb, gpw, imgl)
-                    assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, lit, reg, wpb, gpw, imgl)
-                for k in ("ACME_COOP_LITERAL", "ACME_COOP_REG", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL"):
+                    assert np.array_equal(y, outs["coop, literal" if lit == "1" else "coop"]), (name, lit, wpb, gpw, imgl)
+                    assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, lit, wpb, gpw, imgl)
+                for k in ("ACME_COOP_LITERAL", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL"):
                     monkeypatch.delenv(k)
             assert np.abs(outs["coop, literal"] - outs["lane per instance"]).max() <= 1e-13 * max(1.0, np.abs(yref).max()), name
             assert np.abs(outs["coop"] - outs["coop, literal"]).max() <= RTOL_SAME * max(1.0, np.abs(yref).max()), name

@@ -877,18 +877,21 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
     """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 18 / 27 / 22 (ties) / 34 / 20 unknowns (what the reference's LU
     "for sizes up to about 60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full
     waves and a ragged last one): the oracle's outputs (RTOL_SAME) and iteration totals.
-    17 ... 32 unknowns run the THRESHOLD path by default (elimination in a learnt row order, |l| <= 8: the a-13 deviation the
+    17 ... 32 unknowns run the register instantiations (elimination in a learnt row order, |l| <= 8: the a-13 deviation the
     tuned kernels make) -- held to the oracle at RTOL_SAME with the oracle's iteration totals, to the same bits in every
-    launch shape, for a lone instance, a ragged block and private images.  ACME_COOP_LITERAL=1 selects the reference's
-    pivoting literally: every instantiation of it (factorisation in registers, everything in LDS = what 33 ... 64 unknowns
-    use) in every launch shape gives the same bits as every other and agrees with the lane-per-instance kernel entry by entry."""
+    launch shape (1, 2 and 4 instances per wave; waves per block; image in LDS or L2), for 1 / 2 / 3 / 17 instances, private
+    images and a run cut into single-sample launches.  ACME_COOP_LITERAL=1 selects the reference's pivoting literally (the
+    any-size instantiation, everything in LDS: what 33 ... 64 unknowns always run): in every launch shape the same bits, and
+    the lane-per-instance kernel's entry by entry."""
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
-    pins = ("ACME_COOP_REG", "ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL")
+    pins = ("ACME_COOP_WPB", "ACME_COOP_GPW", "ACME_COOP_IMGL")
+    shapes = ("110", "120", "140", "241", "321", "441", "420", "411")
 
-    def split_run(r, u):
-        return np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+    def split_run(r, u, cuts=(50,)):
+        edges = (0,) + tuple(cuts) + (u.shape[2],)
+        return np.concatenate([r.run(u[:, :, a:b]) for a, b in zip(edges, edges[1:])], axis=2)
 
     for name, m, u5 in mid_size_models(more=True) + beyond_the_tuned_shapes()[:1]:
         N, T = 70, u5.shape[2]
@@ -901,7 +904,7 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             y = split_run(r, u)
             err = assert_close(y, yref, rtol=RTOL_SAME)
             assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver)
-            # a lone instance (one group of one wave of a four-wave block) and 17 (a ragged second block): the same bits
+            # a lone instance (one group of one wave of a four-wave block), two, three, and 17 (a ragged second block): the same bits
             for few in (1, 2, 3, 17):
                 rf = ModelRunner(m, few, lib=hip_lib)
                 assert np.array_equal(y[:few], split_run(rf, u[:few])), (name, solver, few)
@@ -909,11 +912,14 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             rp = ModelRunner(m, N, lib=hip_lib, models=[m] * N)
             assert rp.kernel_family() == "coop"
             assert np.array_equal(y, split_run(rp, u)), (name, solver, "private images")
-            # the default path in every launch shape (waves per block sharing the staged tables / image, instances per wave
-            # -- 1, 2 and 4: ADVICE r5 --, image in LDS or in L2; by default whatever keeps most instances resident,
-            # csrc/acme_api.inc coop_shape; a pinned shape that does not fit is ignored): the same bits
-            for shape in ("110", "120", "140", "241", "321", "441", "420", "411"):
-                for k, v in zip(pins, ("1",) + tuple(shape)):
+            # one launch per sample over the first 40 (state, solution caches and learnt row orders cross every boundary)
+            r1 = ModelRunner(m, N, lib=hip_lib)
+            assert np.array_equal(y[:, :, :40], split_run(r1, u[:, :, :40], cuts=tuple(range(1, 40)))), (name, solver, "single-sample launches")
+            # every launch shape (waves per block sharing the staged tables / image, instances per wave -- 1, 2 and 4: ADVICE
+            # r5 --, image in LDS or in L2; by default whatever keeps most instances resident, csrc/acme_api.inc coop_shape; a
+            # pinned shape that does not fit is ignored): the same bits
+            for shape in shapes:
+                for k, v in zip(pins, shape):
                     monkeypatch.setenv(k, v)
                 rl = ModelRunner(m, N, lib=hip_lib)
                 assert rl.kernel_family() == "coop"
@@ -922,23 +928,22 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
                 assert np.array_equal(y, yl), (name, solver, "default path", shape)
             for k in pins:
                 monkeypatch.delenv(k)
-            # the reference's pivoting literally: every instantiation in every launch shape, the same bits
+            # the reference's pivoting literally (the any-size instantiation): in every launch shape the same bits
             monkeypatch.setenv("ACME_COOP_LITERAL", "1")
             ylit = None
-            for reg in ("1", "0"):
-                for shape in ("", "110", "120", "140", "241", "321", "441", "420", "411"):
-                    for k, v in zip(pins, (reg,) + tuple(shape)):
-                        monkeypatch.setenv(k, v)
-                    rl = ModelRunner(m, N, lib=hip_lib)
-                    assert rl.kernel_family() == "coop"
-                    yl = split_run(rl, u)
-                    assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, reg, shape)
-                    if ylit is None:
-                        ylit = yl
-                        assert_close(ylit, yref, rtol=RTOL_SAME)
-                    assert np.array_equal(ylit, yl), (name, solver, "registers" if reg == "1" else "LDS", shape)
-                    for k in pins:
-                        monkeypatch.delenv(k, raising=False)
+            for shape in ("",) + shapes:
+                for k, v in zip(pins, shape):
+                    monkeypatch.setenv(k, v)
+                rl = ModelRunner(m, N, lib=hip_lib)
+                assert rl.kernel_family() == "coop"
+                yl = split_run(rl, u)
+                assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, "literal", shape)
+                if ylit is None:
+                    ylit = yl
+                    assert_close(ylit, yref, rtol=RTOL_SAME)
+                assert np.array_equal(ylit, yl), (name, solver, "literal", shape)
+                for k in pins:
+                    monkeypatch.delenv(k, raising=False)
             monkeypatch.delenv("ACME_COOP_LITERAL")
             monkeypatch.setenv("ACME_COOP", "0")
             r0 = ModelRunner(m, N, lib=hip_lib)
