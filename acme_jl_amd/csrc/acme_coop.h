@@ -820,6 +820,7 @@ ACME_DEV void coop_linearize(const CoopCtx &c, const GenSub &s, CoopSolver &f, i
         if (phase == 0) {
             learn = act && finite && trip;
             if (ACME_USUAL(wv::ballot(learn) == 0ull)) break;
+            ACME_DBG("coop relearn: instance %lld lane %d learn %d", c.i, c.lig, (int)learn);
             phase = 1;
             continue;
         }

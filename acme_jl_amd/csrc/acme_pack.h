@@ -388,10 +388,12 @@ inline bool describe_element(int kind, const double *p, int er, int q0_, double 
 }
 
 inline bool pack_model(const HostModel &m_in, Packed &P, std::string &err, const Dims *force_shape = nullptr,
-                       const Packed *force_plan = nullptr) {
+                       const Packed *force_plan = nullptr, bool allow_condense = true) {
     // Condensation (see CondPlan): decided here, once per model -- per-instance models of a batch take the batch
     // model's plan (force_plan) so that they share its element table and lane assignment.  ACME_CONDENSE=0 in the
-    // environment keeps the plain kernel (A/B measurements, tests of the uncondensed path).
+    // environment keeps the plain kernel (A/B measurements, tests of the uncondensed path), and so does allow_condense =
+    // false: a batch whose instances turn out to differ in their element parameters (acme_batch_set_matrices) is rebuilt
+    // on the plain shape, the condensed kernels have no per-instance element tables.
     for (int i = 0; i < GROUP; ++i) P.zperm[i] = P.zinv[i] = i;
     P.lrows.clear();
     P.lcols.clear();
@@ -400,7 +402,7 @@ inline bool pack_model(const HostModel &m_in, Packed &P, std::string &err, const
     int nl_model = 0;
     {
         const char *e = getenv("ACME_CONDENSE");
-        const bool allowed = !(e && e[0] == '0') && m_in.subs.size() == 1 && (!force_shape || force_shape->nl > 0);
+        const bool allowed = allow_condense && !(e && e[0] == '0') && m_in.subs.size() == 1 && (!force_shape || force_shape->nl > 0);
         CondPlan plan;
         bool have = false;
         if (allowed && force_plan && !force_plan->lrows.empty()) {

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "acme_last_error", "acme_device_count", "acme_default_options", "acme_model_create",
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape", "acme_model_kernel_variant",
-    "acme_batch_create", "acme_batch_destroy", "acme_batch_set_matrices", "acme_batch_run",
+    "acme_batch_create", "acme_batch_destroy", "acme_batch_kernel_variant", "acme_batch_set_matrices", "acme_batch_run",
     "acme_batch_run_async", "acme_batch_wait", "acme_batch_set_host_retention", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
     "acme_batch_set_balance", "acme_batch_get_placement",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
@@ -114,6 +114,7 @@ class Library:
         L.acme_batch_create.argtypes = [vp, C.c_longlong, C.POINTER(Options), C.POINTER(vp)]
         L.acme_batch_destroy.argtypes = [vp]
         L.acme_batch_destroy.restype = None
+        L.acme_batch_kernel_variant.argtypes = [vp, ip, ip]
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_run_async.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
@@ -536,7 +537,17 @@ class ModelRunner:
         return self._mh.kernel_variant()
 
     def kernel_family(self):
-        return self._mh.kernel_family()
+        """the kernel family THIS BATCH runs in ("tuned", "generic", "coop"): its model's, unless acme_batch_set_matrices moved
+        it (instances with element parameters of their own)"""
+        fam = C.c_int(0)
+        self.lib.check(self.lib.L.acme_batch_kernel_variant(self.h, None, C.byref(fam)))
+        return ("tuned", "generic", "coop")[fam.value]
+
+    def batch_kernel_variant(self):
+        """(condensed_rows, family) of the batch as it runs now (``acme_batch_kernel_variant``)"""
+        nl, fam = C.c_int(0), C.c_int(0)
+        self.lib.check(self.lib.L.acme_batch_kernel_variant(self.h, C.byref(nl), C.byref(fam)))
+        return nl.value, ("tuned", "generic", "coop")[fam.value]
 
 
 class MultiDeviceRunner:

@@ -181,6 +181,39 @@ def pmc_fp64_executed_flops(r):
                    + (r.get("sq_insts_valu_add_f64_per_launch") or 0.0) + (r.get("sq_insts_valu_trans_f64_per_launch") or 0.0))
 
 
+def pmc_exec_lane_frac(r):
+    """mean share of a VALU instruction's 64 lanes that EXEC had switched on: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"""
+    if r is None or not r.get("sq_thread_cycles_valu_per_launch") or not r.get("sq_active_inst_valu_per_launch"):
+        return None
+    return r["sq_thread_cycles_valu_per_launch"] / (64.0 * r["sq_active_inst_valu_per_launch"])
+
+
+def lanes_with_rows_frac(model, runner):
+    """Share of a 16-lane row's lanes that hold a row of the sub-problem in the 16-lane kernels (the others execute the
+    same instructions on padding: structural, no counter sees it): (all rows / 16, rows in the Newton pass's elimination / 16
+    -- the condensed shapes eliminate only the nonlinear rows there).  None for the lane-per-instance kernels."""
+    if not model.subs or runner.kernel_family() == "generic":
+        return None
+    shape = runner.kernel_shape()
+    nl, _ = runner.kernel_variant()
+    nn = model.subs[0].nn
+    if runner.kernel_family() == "coop":
+        return (nn / (16.0 * -(-nn // 16)),) * 2
+    if shape in ((2, 4, 1, 1, 1, 1), (2, 4, 2, 3, 1, 1)) and os.environ.get("ACME_LANE_KERNEL") != "0":
+        return None
+    return (nn / 16.0, (nn - nl) / 16.0)
+
+
+def fp64_useful(executed_frac, r, rows):
+    """fp64 utilisation with the idle lanes taken out: executed x EXEC-active share (counters) x share
+    of the lanes that hold a row (structure).  An UPPER bound still: within the Newton pass of the condensed shapes only
+    (nn - nl) / 16 of the lanes eliminate."""
+    lf = pmc_exec_lane_frac(r)
+    if executed_frac is None or lf is None or rows is None:
+        return None
+    return executed_frac * lf * rows[0]
+
+
 def algorithmic_bytes(model, n, T):
     """8*(nu+ny) bytes per instance*sample + per-launch state/model traffic."""
     s = model.subs[0] if model.subs else None
@@ -283,7 +316,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
+def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS, light=False):
     """Time the CPU oracle on a bounded, evenly spread sample of the same workload: one
     worker process per host core, `per_core` instance streams of T_cpu samples each (the
     reference's DiscreteModel is single-threaded and non-re-entrant, so independent per-core
@@ -314,8 +347,9 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
         # over the same signal gives the warm-state figure
         res = pool.map(_cpu_worker, jobs(True, None), chunksize=1)
     # leg 2: the same source built -O3 -march=native on this host, on a third of the streams -- in FRESH
-    # worker processes (and _cpu_worker asserts which build it has loaded)
-    native = build_native_oracle()
+    # worker processes (and _cpu_worker asserts which build it has loaded).  (light: the other workloads' bounded
+    # baselines -- config.other_workloads[*].cpu_baseline -- skip it: a few seconds each, not a minute)
+    native = None if light else build_native_oracle()
     res_n = None
     if native:
         with mp.get_context("fork").Pool(cores) as pool:
@@ -349,16 +383,16 @@ def cpu_baseline(fixture, model, pots, amp, T_cpu, per_core=24, fs=FS):
     return out
 
 
-def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3):
+def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3, with_cpu=True, n=None, T=None):
     """One short steady-state measurement of another BASELINE configuration (config.other_workloads; never `value`):
     the same procedure as the headline's timed steps -- fresh batch, `warmup` launches continuing into `steps` timed
     ones -- at the configuration's own size and solver stack."""
     import torch
     from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel, HomotopySolver
     from acme_jl_amd.runner import ModelRunner
-    n = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(workload, 8192)
+    n = n or {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(workload, 8192)
     fs = 176400 if workload == "birdie_grid" else FS
-    T = fs // 10 if workload == "clipper_chain_20" else fs
+    T = T or (fs // 10 if workload == "clipper_chain_20" else fs)
     solver = HomotopySolver if workload == "birdie_grid" else CachingHomotopySolver
     fixture, pots, amp = grid_inputs(workload, 0, 1, n, T)
     model = workload_model(workload, fixture, solver, fs)
@@ -391,13 +425,110 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3):
             "algorithmic_bytes_per_launch": abytes, "traffic": pmc_traffic(prec), "valu_issue_frac": pmc_valu_issue_frac(prec),
             "lds_bank_conflict_frac": pmc_lds_bank_conflict_frac(prec),
             "fp64_executed_tflops": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12) if fx else None,
+            "exec_active_lane_frac": pmc_exec_lane_frac(prec), "lanes_with_rows_frac": lanes_with_rows_frac(model, runner),
+            "fp64_useful_frac": fp64_useful((fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if fx else None, prec,
+                                            lanes_with_rows_frac(model, runner)),
+            "wave_wait_frac": (prec["sq_wait_any_per_launch"] / prec["sq_wave_cycles_per_launch"])
+            if prec and prec.get("sq_wait_any_per_launch") is not None and prec.get("sq_wave_cycles_per_launch") else None,
             "profiled_kernel_ms": (prec or {}).get("kernel_avg_ms_profiled")}
+    cpu = None
+    if with_cpu:
+        # the CPU oracle on a bounded sample of the SAME synthetic inputs (a tenth of a second of signal, four
+        # streams per core spread over the sweep: seconds, so that the default run still ends within minutes)
+        try:
+            cpu = cpu_baseline(fixture, model, pots, amp, fs // 10, per_core=4, fs=fs, light=True)
+        except Exception as e:
+            cpu = {"error": repr(e)}
     return {"workload": workload, "roofline": roof, "config": {"diodeclipper_sweep": 2, "superover_montecarlo": 4, "birdie_grid": 5}.get(workload),
+            "cpu_baseline": cpu,
+            "waves_per_simd": waves_per_simd(runner, n),
             "instances": n, "samples_per_step": T, "fs": fs, "solver": model.solver, "steps": steps, "warmup": warmup,
             "value": n * T * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": kms,
             "kernel": kname,
             "newton_iters_per_sample": float(ra["iters_total"].sum()) / (n * T * steps), "n_warn": float(ra["n_warn"].sum()),
             "y_abs_sum": float(torch.nan_to_num(y).abs().sum())}
+
+
+def waves_per_simd(runner, n, n_simd=1024):
+    """resident wavefronts per SIMD this batch puts on the chip (256 CUs x 4 SIMDs): 16 lanes per instance in the tuned and
+    the mid-size kernels (4 instances per wave), one lane per instance in the generic kernel; the lane-per-instance kernel
+    of the two smallest shapes spreads its instances thin (csrc/acme_lane_kernel.h: 4 ... 64 per wave, the launcher's
+    choice) and is reported as a range"""
+    fam = runner.kernel_family()
+    if fam == "generic":
+        return -(-n // 64) / n_simd
+    shape = runner.kernel_shape()
+    if fam == "tuned" and shape in ((2, 4, 1, 1, 1, 1), (2, 4, 2, 3, 1, 1)) and os.environ.get("ACME_LANE_KERNEL") != "0":
+        return [-(-n // 64) / n_simd, -(-n // 4) / n_simd]
+    return -(-n // 4) / n_simd
+
+
+def literal_grid_leg(local_rank, dev, T=160):
+    """SURVEY 8(d)'s LITERAL config-3 grid -- drive in linspace(0, 1, 32) exactly (test/runtests.jl:778) -- which `value`
+    does not run: its last column (256 of 8 192 instances) sits on the singular drive = 1.0 corner of the variable-pot
+    model, where the reference's solver stack fails after ~900 Newton iterations on practically every sample and warns
+    (src/ACME.jl:688-690) -- a launch lasts as long as its slowest wave.  With acme_batch_set_isolation the library runs
+    the instances it has seen misbehave in a launch of their own: reported are the rate at which the 7 936 healthy
+    instances complete on the caller's stream, the whole grid's rate, and the singular column's warnings.  A few hundred
+    samples only: a singular cell costs ~50 ms of GPU time per sample."""
+    import torch
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ModelRunner
+    N = 8192
+    model = workload_model("superover_grid", "superover_var", CachingHomotopySolver)
+    idx = np.arange(N)
+    pots = np.stack([(idx // 256) / 31.0, ((idx // 16) % 16) / 15.0, (idx % 16) / 15.0], axis=1)
+    healthy = pots[:, 0] < 1.0
+    u = make_u(torch, dev, model, pots, 1.0, N, T)
+    r = ModelRunner(model, N, device=local_rank)
+    r.set_isolation(50.0)
+    out = {"workload": "superover_grid_literal", "instances": N, "samples_per_step": T, "solver": model.solver,
+           "singular_instances": int((~healthy).sum())}
+    for step in ("classifying", "isolated"):       # the first run measures who is slow, the second runs them apart
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = r.run_torch(u)
+        torch.cuda.current_stream().synchronize()
+        t_stream = time.perf_counter() - t0
+        r.wait(check=False)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        out[step + "_ms_callers_stream"] = 1e3 * t_stream
+        out[step + "_ms_everything"] = 1e3 * t_all
+    ra = {k: np.asarray(v) for k, v in r.report_arrays().items()}
+    hm = healthy
+    out.update(value_healthy_instances=int(healthy.sum()) * T / t_stream, value_whole_grid=N * T / t_all,
+               n_warn_singular_column=float(ra["n_warn"][~hm].sum()), n_warn_healthy=float(ra["n_warn"][hm].sum()),
+               samples_of_the_singular_column=int((~healthy).sum()) * T * 2,
+               newton_iters_per_sample_singular=float(ra["iters_total"][~hm].sum()) / (int((~healthy).sum()) * T * 2),
+               newton_iters_per_sample_healthy=float(ra["iters_total"][hm].sum()) / (int(healthy.sum()) * T * 2),
+               y_finite=bool(torch.isfinite(y).all()),
+               note="drive = linspace(0, 1, 32): value_healthy_instances = the 7 936 instances with drive < 1 x samples / time until "
+                    "the caller's stream is done (second run: acme_batch_set_isolation(50) has moved the singular column to a "
+                    "launch of its own); the reference warns on (practically) every sample of the singular column and carries on "
+                    "(src/ACME.jl:688-690), as this library does: n_warn_singular_column of samples_of_the_singular_column")
+    return out
+
+
+def saturation_curve(local_rank, dev, factors=(1, 2, 4, 8)):
+    """--saturation: every workload at 1 x, 2 x, 4 x, 8 x its BASELINE per-GPU instance count (config 5 at 8 x is ALL of its
+    16 384 instances on one GPU), a quarter of a second of signal per step, steady state: where one chip saturates, and
+    hence when sharding a sweep over more GPUs stops paying.  config.saturation; never `value`."""
+    import torch
+    rows = []
+    for wl, base in (("superover_grid", 8192), ("diodeclipper_sweep", 4096), ("superover_montecarlo", 8192), ("birdie_grid", 2048),
+                     ("clipper_chain_20", 8192)):
+        fs = 176400 if wl == "birdie_grid" else FS
+        for f in factors:
+            try:
+                r = other_workload_leg(wl, local_rank, dev, steps=2, warmup=2, with_cpu=False, n=base * f,
+                                       T=fs // 10 if wl == "clipper_chain_20" else fs // 4)
+                rows.append({k: r[k] for k in ("workload", "config", "instances", "samples_per_step", "value", "ms_per_step", "kernel_ms",
+                                               "newton_iters_per_sample", "waves_per_simd")} | {"factor": f})
+            except Exception as e:
+                rows.append({"workload": wl, "factor": f, "instances": base * f, "error": repr(e)[:200]})
+            torch.cuda.empty_cache()
+    return rows
 
 
 def host_buffer_leg(runner, u, N, T, model):
@@ -495,6 +626,11 @@ def main():
                     help="skip the host-buffer leg (config.value_host_buffers: run! through acme_batch_run(ACME_MEM_HOST), "
                          "what the Julia binding calls)")
     ap.add_argument("--cpu-samples", type=int, default=None)
+    ap.add_argument("--saturation", action="store_true",
+                    help="also measure every workload at 1 / 2 / 4 / 8 x its BASELINE per-GPU instance count (config.saturation; "
+                         "several minutes; all 16 384 instances of config 5 on one GPU among them)")
+    ap.add_argument("--no-literal-grid", action="store_true",
+                    help="skip the leg on the LITERAL config-3 grid, drive = linspace(0, 1, 32) with its singular column (config.literal_grid)")
     args = ap.parse_args()
 
     import torch
@@ -650,6 +786,14 @@ def main():
                 others.append(other_workload_leg(wl, local_rank, dev))
             except Exception as e:      # (the headline line must come out whatever happens here)
                 others.append({"workload": wl, "error": repr(e)})
+    literal = saturation = None
+    if world == 1 and args.workload == "superover_grid" and not args.no_other_workloads and not args.no_literal_grid:
+        try:
+            literal = literal_grid_leg(local_rank, dev)
+        except Exception as e:
+            literal = {"workload": "superover_grid_literal", "error": repr(e)}
+    if world == 1 and args.saturation:
+        saturation = saturation_curve(local_rank, dev)
     if rank == 0:
         units = world * n_per_gpu * T * args.steps
         value = units / elapsed
@@ -701,6 +845,11 @@ def main():
                 "value_host_buffers": host["steady_value"] if host else None,
                 "host_buffers": host,
                 "other_workloads": others,
+                "literal_grid": literal,
+                "saturation": saturation,
+                "grid_note": "`value` runs drive = i/32 (i = 0 ... 31): SURVEY 8(d) quotes linspace(0, 1, 32), whose last column "
+                             "(drive = 1.0) is a singular corner of the variable-pot model where the reference warns on every sample; "
+                             "config.literal_grid has that grid, with acme_batch_set_isolation",
                 "timed_steps_note": "the timed steps continue the signal of the warm-up steps: warm solver state and "
                                     "solution caches (steady state); cold_first_step_ms is the first step of the fresh batch",
                 "newton_iters_per_sample": iters_per_sample, "iters_max": iters_max,
@@ -723,6 +872,15 @@ def main():
                         "work-equivalent rate, not utilisation",
                 "fp64_executed_tflops": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12) if fx else None,
                 "fp64_executed_frac": (fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if fx else None,
+                "exec_active_lane_frac": pmc_exec_lane_frac(prec),
+                "lanes_with_rows_frac": lanes_with_rows_frac(model, runner),
+                "fp64_useful_frac": fp64_useful((fx / (prec["kernel_avg_ms_profiled"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if fx else None, prec,
+                                                lanes_with_rows_frac(model, runner)),
+                "fp64_useful_note": "fp64_executed_frac x exec_active_lane_frac (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU: lanes EXEC "
+                                    "had switched on) x lanes_with_rows_frac[0] (lanes of a 16-lane row that hold a row of the sub-problem; "
+                                    "[1]: the share that eliminates in the Newton pass of a condensed shape): the kernels predicate with "
+                                    "selects, not with EXEC, so the counters see nearly all lanes active and the structural factor is what "
+                                    "takes the padding lanes out -- an upper bound of useful fp64",
                 "fp64_reference_equivalent_tflops": algorithmic_flops(model, iters_per_sample) * n_per_gpu * T
                 / (last_ms * 1e-3) / 1e12 if model.subs else None,
                 "fp64_peak_tflops": FP64_PEAK_TFLOPS,

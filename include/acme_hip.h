@@ -133,6 +133,12 @@ int acme_model_kernel_variant(const acme_model *m, int *condensed_rows, int *gen
 int acme_batch_create(const acme_model *m, long long n_instances, const acme_options *opts,
                       acme_batch **out);
 void acme_batch_destroy(acme_batch *b);
+/* which kernel variant THIS BATCH runs in, as acme_model_kernel_variant reports it for a model (*family: 0 tuned shape, 1
+ * lane-per-instance generic kernel, 2 cooperative mid-size kernel).  It can differ from its model's: instances with element
+ * parameters of their own (acme_batch_set_matrices) move a batch off the condensed shape (the library rebuilds it on the
+ * plain shape by itself: the reference's models each carry their own closures, src/elements.jl:236-245,309-406) and a
+ * mid-size batch to the lane-per-instance kernel.  Either pointer may be null. */
+int acme_batch_kernel_variant(const acme_batch *b, int *condensed_rows, int *family);
 
 /* per-instance matrices (Monte-Carlo component tolerances, sweeps over element parameters): instance i uses the
  * matrices AND the element closures' parameters of models[i] -- in the reference every model carries its own element

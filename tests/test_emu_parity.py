@@ -1014,31 +1014,61 @@ def test_emulated_per_instance_element_parameters(emu_lib):
         ModelRunner(models[0], 2, lib=emu_lib, models=[models[0], DiscreteModel(examples.diodeclipper(), Fraction(1, 44100), HS)])
 
 
-def test_emulated_per_instance_elements_and_condensed_shapes(emu_lib, monkeypatch):
-    """The condensed kernel shapes (potentiometers as inputs) do not carry the per-instance element path (it cost the
-    headline kernel 0.8 % by its mere presence): a batch of superover models with their own diode parameters is refused
-    there with a message naming the way out, and runs on the plain 13 x 13 shape (ACME_CONDENSE=0) against each model's
-    own oracle run."""
+def superover_models_with_their_own_diodes(n, solver):
+    """n superover models (pots as inputs) that differ in their diodes' saturation currents only"""
     import copy
-    from acme_jl_amd.runner import AcmeError, ModelRunner
-    from helpers import HS, RTOL_SAME
-    base = load("superover_var", HS)
+    base = load("superover_var", solver)
     models = []
-    for k in range(3):
+    for k in range(n):
         m = copy.deepcopy(base)
         for e in m.subs[0].table:
             if e["kind"] == 1:                     # the diodes: another saturation current per instance
                 e["par"] = [e["par"][0] * (1.0 + 0.5 * k), e["par"][1]]
         models.append(m)
+    return models
+
+
+def test_emulated_per_instance_elements_and_condensed_shapes(emu_lib, monkeypatch):
+    """The condensed kernel shapes (potentiometers as inputs) do not carry the per-instance element path (it cost the
+    headline kernel 0.8 % by its mere presence).  A batch of superover models with their own diode parameters moves to the
+    plain 13 x 13 shape BY ITSELF (the library chooses, not the environment) -- whether the differing
+    models come with the first acme_batch_set_matrices call, with a later one (the instances set before keep their models),
+    or after the batch has run (every instance keeps its state) -- and matches each model's own oracle run;
+    acme_batch_kernel_variant reports the move."""
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL_SAME
+    models = superover_models_with_their_own_diodes(3, HS)
     u = sweep_inputs("superover_var", 3, 60, seed=2)
-    with pytest.raises(AcmeError, match="ACME_CONDENSE=0"):
-        ModelRunner(models[0], 3, lib=emu_lib, models=models)
-    monkeypatch.setenv("ACME_CONDENSE", "0")
+    ref = [oracle_run(m, u[k:k + 1]) for k, m in enumerate(models)]
+
+    def check(r, y, ks=range(3)):
+        for k in ks:
+            assert_close(y[k:k + 1], ref[k][0], rtol=RTOL_SAME)
+            assert r.report_arrays()["iters_total"][k] == ref[k][1][0], k
+    # all at once
     r = ModelRunner(models[0], 3, lib=emu_lib, models=models)
-    assert r.kernel_variant()[0] == 0
+    assert r.kernel_variant()[0] > 0 and r.batch_kernel_variant() == (0, "tuned")      # the MODEL condenses, the batch has moved
     y = r.run(u)
-    for k, m in enumerate(models):
-        yref, its = oracle_run(m, u[k:k + 1])
-        assert_close(y[k:k + 1], yref, rtol=RTOL_SAME)
-        assert r.report_arrays()["iters_total"][k] == its[0]
+    check(r, y)
     assert np.abs(y[0] - y[2]).max() > 1e-9
+    # in two calls: equal models first (the batch stays condensed), then the ones that differ
+    r2 = ModelRunner(models[0], 3, lib=emu_lib, models=[models[0]] * 3)
+    assert r2.batch_kernel_variant()[0] > 0
+    r2.set_models(2, [models[2]])
+    assert r2.batch_kernel_variant() == (0, "tuned")
+    r2.set_models(1, [models[1]])
+    y2 = r2.run(u)
+    assert np.array_equal(y2, y)
+    # after the batch has run: instance 0's state survives the move, instance 2 restarts as its new model
+    r3 = ModelRunner(models[0], 3, lib=emu_lib, models=[models[0]] * 3)
+    ya = r3.run(u[:, :, :25])
+    r3.set_models(2, [models[2]])
+    assert r3.batch_kernel_variant() == (0, "tuned")
+    yb = r3.run(u[:, :, 25:])
+    assert_close(np.concatenate([ya[:1], yb[:1]], axis=2), ref[0][0], rtol=RTOL_SAME)
+    assert_close(yb[2:3], oracle_run(models[2], u[2:3, :, 25:])[0], rtol=RTOL_SAME)
+    # the plain shape from the start (ACME_CONDENSE=0) is where the batch ends up
+    monkeypatch.setenv("ACME_CONDENSE", "0")
+    r0 = ModelRunner(models[0], 3, lib=emu_lib, models=models)
+    assert r0.kernel_variant()[0] == 0
+    assert np.array_equal(r0.run(u), y)

@@ -176,7 +176,21 @@ def test_per_instance_element_parameters(hip_lib):
         assert its[k] == iref[0], k
     print(f"64 diode clippers with their own is / eta in one batch ({r.kernel_shape()}): worst rel err vs the exact models' oracle {worst:.2e}, "
           f"identical iteration totals")
-    from test_emu_parity import element_parameter_sweeps
+    # superover with the pots as inputs (the headline model: a CONDENSED kernel shape) and per-instance diode saturation
+    # currents: the library moves the batch to the plain shape by itself -- no environment variable
+    from test_emu_parity import element_parameter_sweeps, superover_models_with_their_own_diodes
+    from helpers import sweep_inputs
+    sm = superover_models_with_their_own_diodes(20, HS)
+    us = sweep_inputs("superover_var", 20, 400, seed=2)
+    rs = ModelRunner(sm[0], 20, lib=hip_lib, models=sm)
+    assert rs.kernel_variant()[0] > 0 and rs.batch_kernel_variant() == (0, "tuned")
+    ys = np.concatenate([rs.run(us[:, :, :150]), rs.run(us[:, :, 150:])], axis=2)
+    for k, m in enumerate(sm):
+        yref, iref = oracle_run(m, us[k:k + 1])
+        assert_close(ys[k:k + 1], yref, rtol=RTOL_SAME)
+        assert rs.report_arrays()["iters_total"][k] == iref[0], k
+    print("20 superover models (pots as inputs) with their own diode saturation currents: batch moved off the condensed shape by itself, "
+          f"kernel shape {rs.kernel_shape()}, oracle's outputs and iteration totals")
     name, gp, ugp = element_parameter_sweeps()[1]
     rg = ModelRunner(gp[0], len(gp), lib=hip_lib, models=gp)
     yg = rg.run(ugp)

@@ -125,7 +125,7 @@ def test_binding_covers_the_abi_it_documents():
     """every entry point a Julia host needs is bound (the kernel-timing helpers are bench-only)"""
     bound = {c["sym"] for c in julia_ccalls()}
     need = set(c_prototypes()) - {"acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_default_options",
-                                  "acme_model_set_row_order", "acme_model_kernel_shape", "acme_model_kernel_variant", "acme_batch_get_placement",
+                                  "acme_model_set_row_order", "acme_model_kernel_shape", "acme_model_kernel_variant", "acme_batch_kernel_variant", "acme_batch_get_placement",
                                   "acme_batch_reset_report"}
     assert need <= bound, need - bound
 

@@ -31,6 +31,9 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS
 echo "== pmc: SQ2 (waits, branches, fetch)"
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQ_WAVES \
     -d "$OUT/pmc_sq2" -o bench -- $BENCH > "$OUT/pmc_sq2.log" 2>&1
+echo "== pmc: lanes (thread-cycles of the VALU instructions against their wave-cycles: EXEC-active lanes)"
+timeout 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU \
+    -d "$OUT/pmc_lanes" -o bench -- $BENCH > "$OUT/pmc_lanes.log" 2>&1
 python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import collections, glob, json, os, shlex, sqlite3, sys
 out = sys.argv[1]
@@ -56,7 +59,7 @@ for f in sorted(glob.glob(out + "/trace/**/*.db", recursive=True)):
               % (len(d), kern["avg_us"], kern["min_us"], kern["max_us"], r[3], r[4], r[5], r[6], r[7], r[8], r[9]))
         print("   kernel: " + r[0])
 vals = {}
-for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64", "pmc_sq2"):
+for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64", "pmc_sq2", "pmc_lanes"):
     for f in sorted(glob.glob(out + f"/{grp}/**/*.db", recursive=True)):
         con = sqlite3.connect(f)
         print("== counters", grp, "(per dispatch, timed steps only)")
@@ -89,6 +92,9 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
            "sq_insts_lds_per_launch": vals.get("SQ_INSTS_LDS"), "sq_insts_branch_per_launch": vals.get("SQ_INSTS_BRANCH"),
            "sq_lds_bank_conflict_per_launch": vals.get("SQ_LDS_BANK_CONFLICT"), "sq_lds_idx_active_per_launch": vals.get("SQ_LDS_IDX_ACTIVE"),
            "grbm_gui_active_per_launch": vals.get("GRBM_GUI_ACTIVE"), "sq_waves": vals.get("SQ_WAVES"),
+           "sq_thread_cycles_valu_per_launch": vals.get("SQ_THREAD_CYCLES_VALU"), "sq_active_inst_valu_per_launch": vals.get("SQ_ACTIVE_INST_VALU"),
+           "sq_wave_cycles_per_launch": vals.get("SQ_WAVE_CYCLES"), "sq_wait_any_per_launch": vals.get("SQ_WAIT_ANY"),
+           "sq_wait_inst_any_per_launch": vals.get("SQ_WAIT_INST_ANY"), "sq_active_inst_any_per_launch": vals.get("SQ_ACTIVE_INST_ANY"),
            "kernel_avg_ms_profiled": kern.get("avg_us", 0.0) / 1e3 if kern else None,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ groups (separate passes) and --kernel-trace --stats; "
                      "means over the dispatches of the TIMED steps of python bench.py --no-cpu-baseline --steps %s --warmup %s %s"
@@ -99,6 +105,11 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         print("lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.4f" % (vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]))
     if vals.get("GRBM_GUI_ACTIVE") and vals.get("SQ_INSTS_VALU"):
         print("valu_issue_frac = SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs / 4) = %.4f" % (vals["SQ_INSTS_VALU"] / (1024 * vals["GRBM_GUI_ACTIVE"] / 8 / 4)))
+    if vals.get("SQ_THREAD_CYCLES_VALU") and vals.get("SQ_ACTIVE_INST_VALU"):
+        print("exec_active_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = %.4f" % (vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"])))
+    if vals.get("SQ_WAVE_CYCLES") and vals.get("SQ_WAIT_ANY") is not None:
+        print("a wave's life: issuing SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = %.3f, waiting SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f, in s_waitcnt SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f"
+              % (vals.get("SQ_ACTIVE_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"], vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"], vals.get("SQ_WAIT_INST_ANY", 0) / vals["SQ_WAVE_CYCLES"]))
     if vals.get("SQ_INSTS_VALU_FMA_F64") is not None and kern:
         fl = 64.0 * (2 * vals["SQ_INSTS_VALU_FMA_F64"] + vals.get("SQ_INSTS_VALU_MUL_F64", 0) + vals.get("SQ_INSTS_VALU_ADD_F64", 0) + vals.get("SQ_INSTS_VALU_TRANS_F64", 0))
         print("executed fp64: 64 lanes x (2 FMA + MUL + ADD + TRANS) = %.4g flop per launch = %.2f TFLOP/s over %.1f ms (masked lanes counted: an upper bound of useful work)"
