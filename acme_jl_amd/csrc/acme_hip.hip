@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -77,6 +78,19 @@ static const std::vector<KernelEntry> &kernel_table() {
 __global__ __launch_bounds__(64) void acme_generic_kernel(GArgs A) {
     const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
     if (i < A.n_inst) gen_main(A, i);
+}
+
+// acme_batch_run_const: the full input rows of a time slice put together in HBM -- row k of sample t of instance i is the
+// row's constant (mask bit k) or the next of the varying rows the caller handed over ([N][pitch][nuv])
+struct ExpandArgs { double *dst; const double *uv, *uc; unsigned long long mask; long long n, T, pitch; int nu, nuv; };
+__global__ __launch_bounds__(256) void acme_expand_kernel(ExpandArgs A) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= A.n * A.T) return;
+    const long long i = idx / A.T, t = idx - i * A.T;
+    const double *src = A.uv + (i * A.pitch + t) * A.nuv, *c = A.uc + i * A.nu;
+    double *dst = A.dst + idx * A.nu;
+    int v = 0;
+    for (int k = 0; k < A.nu; ++k) dst[k] = (A.mask >> k & 1ull) ? c[k] : src[v++];
 }
 
 // placement of the waves by their measured cost (acme_balance.h): one thread per wave
@@ -168,6 +182,11 @@ static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t st) {
     GArgs args = A;
     void *params[] = {&args};
     return ACME_LAUNCH_FN(coop_fn(A), grid, dim3(64 * A.coop_wpb), lds_bytes, st, params);
+}
+static inline int launch_expand(double *dst, const double *uv, const double *uc, unsigned long long mask, long long n, long long T,
+                                long long pitch, int nu, int nuv, stream_t st) {
+    const ExpandArgs A{dst, uv, uc, mask, n, T, pitch, nu, nuv};
+    return ACME_LAUNCH(acme_expand_kernel, dim3((unsigned)((n * T + 255) / 256)), dim3(256), 0, st, A);
 }
 static inline int launch_balance(const BalArgs &A, stream_t st) {
     const unsigned g = (unsigned)((A.nu + 255) / 256);

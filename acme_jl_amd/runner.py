@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "acme_last_error", "acme_device_count", "acme_default_options", "acme_model_create",
     "acme_model_add_subproblem", "acme_model_set_row_order", "acme_model_destroy",
     "acme_model_kernel_shape", "acme_model_kernel_variant",
-    "acme_batch_create", "acme_batch_destroy", "acme_batch_kernel_variant", "acme_batch_set_matrices", "acme_batch_run",
+    "acme_batch_create", "acme_batch_destroy", "acme_batch_kernel_variant", "acme_batch_set_matrices", "acme_batch_run", "acme_batch_run_const",
     "acme_batch_run_async", "acme_batch_wait", "acme_batch_set_host_retention", "acme_batch_release_host_buffers", "acme_batch_set_progress_callback", "acme_batch_set_isolation",
     "acme_batch_set_balance", "acme_batch_get_placement",
     "acme_batch_solve", "acme_batch_get_extrapolation_jacobian", "acme_batch_last_kernel_ms", "acme_batch_kernel_time", "acme_batch_get_report", "acme_batch_reset_report",
@@ -117,6 +117,7 @@ class Library:
         L.acme_batch_kernel_variant.argtypes = [vp, ip, ip]
         L.acme_batch_set_matrices.argtypes = [vp, C.c_longlong, C.c_longlong, C.POINTER(vp)]
         L.acme_batch_run.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
+        L.acme_batch_run_const.argtypes = [vp, vp, vp, C.c_ulonglong, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_run_async.argtypes = [vp, vp, vp, C.c_longlong, C.c_int, vp]
         L.acme_batch_wait.argtypes = [vp]
         L.acme_batch_set_host_retention.argtypes = [vp, C.c_int]
@@ -393,6 +394,37 @@ class ModelRunner:
         if y is not None:
             return y
         return np.asfortranarray(out[0]) if single else np.ascontiguousarray(out)
+
+    def run_const(self, u_var, u_const, const_rows, y=None, check=True):
+        """``run!`` with constant input rows (``acme_batch_run_const``): ``const_rows`` names the input rows that keep one
+        value per instance for the whole call -- ``u_const`` (N, nu): their values (the other entries are ignored) --,
+        ``u_var`` (N, T, nu_var) holds the remaining rows in row order (the ABI's time-major layout).  A sweep over
+        potentiometer positions then moves a quarter of the bytes over the bus; the results are those of ``run`` on the
+        materialised input, bit for bit.  Returns y (N, T, ny)."""
+        m = self.model
+        rows = sorted(set(int(k) for k in const_rows))
+        if any(k < 0 or k >= m.nu for k in rows):
+            raise DimensionMismatch(f"constant rows {rows} of a model with {m.nu} inputs")
+        mask = 0
+        for k in rows:
+            mask |= 1 << k
+        nuv = m.nu - len(rows)
+        u_var = np.ascontiguousarray(u_var, dtype=np.float64)
+        u_const = np.ascontiguousarray(u_const, dtype=np.float64)
+        if u_var.ndim != 3 or u_var.shape[0] != self.n or u_var.shape[2] != nuv:
+            raise DimensionMismatch(f"u_var must have shape ({self.n}, T, {nuv})")
+        if u_const.shape != (self.n, m.nu):
+            raise DimensionMismatch(f"u_const must have shape ({self.n}, {m.nu})")
+        T = u_var.shape[1]
+        if y is None:
+            y = np.empty((self.n, T, m.ny), dtype=np.float64)
+        elif not (isinstance(y, np.ndarray) and y.dtype == np.float64 and y.flags.c_contiguous and y.shape == (self.n, T, m.ny)):
+            raise DimensionMismatch(f"y must be a C-contiguous float64 array of shape ({self.n}, {T}, {m.ny})")
+        self.lib.check(self.lib.L.acme_batch_run_const(self.h, u_var.ctypes.data, u_const.ctypes.data, mask, y.ctypes.data, T, ACME_MEM_HOST, None))
+        self._hold(u_var, u_const, y)
+        if check:
+            self.check()
+        return y
 
     def run_async(self, u, y):
         """``acme_batch_run_async`` on host buffers in the ABI's layout: ``u`` (N, T, nu) and ``y``

@@ -163,6 +163,17 @@ int acme_batch_set_matrices(acme_batch *b, long long first, long long count,
  * hipStream_t to launch on (NULL = default stream); the call is then asynchronous. */
 int acme_batch_run(acme_batch *b, const double *u, double *y, long long T, int mem,
                    void *stream);
+/* run! with CONSTANT input rows (src/ACME.jl:672-674 copies column n of u into ucur sample by sample: a row that never
+ * changes -- a potentiometer position, a supply voltage, a mix control of a parameter sweep -- need not be materialised
+ * T times).  const_mask: bit k set = input row k keeps the value u_const[i * nu + k] (u_const: [N][nu], the entries of
+ * the other rows are ignored) for the whole call; u_var then holds only the rows whose bit is clear, in row order:
+ * [N][T][nu_var] with nu_var = nu - popcount(const_mask).  The full input rows are put together ON THE DEVICE, time
+ * slice by time slice (HBM traffic the kernels do not notice), so a host-buffer run moves nu_var / nu of the bytes
+ * over the bus -- the headline sweep (three pot rows of four inputs): 2.9 instead of 11.6 GB per second of audio.
+ * Results are those of acme_batch_run on the materialised u, bit for bit.  mem / stream as acme_batch_run (u_var and
+ * u_const live where mem says); y: [N][T][ny]. */
+int acme_batch_run_const(acme_batch *b, const double *u_var, const double *u_const, unsigned long long const_mask,
+                         double *y, long long T, int mem, void *stream);
 /* Host-buffer runs and page-locking.  By DEFAULT the library never keeps anything of the caller's arrays beyond the
  * call: u and y are copied from / to ordinary (pageable) memory in time slices that overlap the kernel -- the right
  * thing for one-shot calls and for wrappers whose arrays are per-call temporaries or garbage-collected (locking

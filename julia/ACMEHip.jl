@@ -339,6 +339,35 @@ function run!(r::BatchRunner, u::Array{Float64,3})
     return y
 end
 
+"""
+    run!(r::BatchRunner, y, u_var, u_const, const_rows)
+
+`run!` with CONSTANT input rows: the rows named in `const_rows` (1-based) keep the value `u_const[k, i]` (`u_const`:
+nu x N) for the whole call in instance `i` -- a potentiometer position, a supply voltage -- and `u_var`
+(nu_var x T x N) holds the other rows in row order.  Where the reference copies column `n` of a full `u` into `ucur`
+sample by sample (src/ACME.jl:672-674), the library puts the full rows together on the device: a sweep over three pot
+positions of a four-input model moves a quarter of the bytes over the bus.  Results: those of `run!(r, y, u)` on the
+materialised `u`, bit for bit.
+"""
+function run!(r::BatchRunner, y::Array{Float64,3}, u_var::Array{Float64,3}, u_const::Matrix{Float64}, const_rows)
+    nu = ACME.nu(r.model)
+    mask = UInt64(0)
+    for k in const_rows
+        1 <= k <= nu || throw(DimensionMismatch("constant row $k of a model with $nu inputs"))
+        mask |= UInt64(1) << (k - 1)
+    end
+    nuv = nu - count_ones(mask)
+    size(u_var, 1) == nuv || throw(DimensionMismatch("u_var has $(size(u_var, 1)) rows, $nuv inputs vary"))
+    size(u_const) == (nu, r.n) || throw(DimensionMismatch("u_const must be $nu x $(r.n)"))
+    size(u_var, 3) == r.n && size(y, 3) == r.n || throw(DimensionMismatch("u_var and y must hold $(r.n) instances"))
+    size(y, 1) == ACME.ny(r.model) && size(y, 2) == size(u_var, 2) ||
+        throw(DimensionMismatch("output matrix must be $(ACME.ny(r.model)) x $(size(u_var, 2)) x $(r.n)"))
+    GC.@preserve r check(ccall((:acme_batch_run_const, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Culonglong, Ptr{Cdouble}, Clonglong, Cint, Ptr{Cvoid}),
+                r.h, u_var, u_const, mask, y, size(u_var, 2), ACME_MEM_HOST, C_NULL))
+    return checkreports!(r)
+end
+
 # ---- MultiBatchRunner: N instances over the GPUs of one node, one Julia process -----------------------
 "contiguous instance range (1-based) of part `k` of `parts`; sizes differ by at most one (acme_jl_amd/dist.py)"
 function shard_range(n::Integer, k::Integer, parts::Integer)

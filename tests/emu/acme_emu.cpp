@@ -6,6 +6,7 @@
 #include "wave_emu.h"
 
 #include <chrono>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -281,6 +282,17 @@ static inline int launch_coop(const GArgs &A, size_t lds_bytes, stream_t) {
         CoopLaunch c{&A, lds.data(), (int)b};
         emu::run_block((int)b, &coop_fiber_entry, &c);
     }
+    return 0;
+}
+// acme_batch_run_const: the full input rows of a time slice, put together
+static inline int launch_expand(double *dst, const double *uv, const double *uc, unsigned long long mask, long long n, long long T,
+                                long long pitch, int nu, int nuv, stream_t) {
+    for (long long i = 0; i < n; ++i)
+        for (long long t = 0; t < T; ++t) {
+            int v = 0;
+            for (int k = 0; k < nu; ++k)
+                dst[(i * T + t) * nu + k] = (mask >> k & 1ull) ? uc[i * nu + k] : uv[(i * pitch + t) * nuv + v++];
+        }
     return 0;
 }
 // placement of the waves by their measured cost (acme_balance.h): the two passes, one "thread" after the other

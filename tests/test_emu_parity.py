@@ -965,6 +965,38 @@ def test_emulated_birdie_var_iteration_gap_is_rounding(emu_lib, monkeypatch):
     print("oracle at (17, 38) under ulps of p[0]:", rows38)
 
 
+def test_emulated_constant_input_rows(emu_lib):
+    """acme_batch_run_const: input rows that keep one value per instance for the whole call are handed
+    over once, the others as [N][T][nu_var]; the library puts the full rows together on the device.  The results are those
+    of run on the materialised input, bit for bit -- on the headline model (three potentiometer rows of four inputs; long
+    enough for several time slices), with another choice of rows, with every row constant and with none; wrong shapes are
+    refused."""
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import DimensionMismatch
+    m = load("superover_var", CachingHomotopySolver)
+    N, T = 3, 4200                                   # (4 096 samples and more run in time slices)
+    u = sweep_inputs("superover_var", N, T, seed=3)  # [N][nu][T]: row 0 the signal, rows 1 .. 3 the pots
+    ub = np.ascontiguousarray(u.transpose(0, 2, 1))
+    y_ref = emu_runner(emu_lib, m, N).run(ub, time_major=True)
+    r = emu_runner(emu_lib, m, N)
+    y = r.run_const(ub[:, :, :1], ub[:, 0, :], (1, 2, 3))
+    assert np.array_equal(y, y_ref)
+    # rows 1 and 3 constant, 0 and 2 varying (in row order)
+    r = emu_runner(emu_lib, m, N)
+    assert np.array_equal(r.run_const(ub[:, :300, (0, 2)], ub[:, 0, :], (3, 1)), y_ref[:, :300])
+    # none constant = run; all constant = a constant input
+    r = emu_runner(emu_lib, m, N)
+    assert np.array_equal(r.run_const(ub[:, :300], ub[:, 0, :], ()), y_ref[:, :300])
+    uc = ub[:, :200].copy()
+    uc[:, :, 0] = 0.3
+    r = emu_runner(emu_lib, m, N)
+    assert np.array_equal(r.run_const(np.zeros((N, 200, 0)), uc[:, 0, :], (0, 1, 2, 3)), emu_runner(emu_lib, m, N).run(uc, time_major=True))
+    with pytest.raises(DimensionMismatch):
+        emu_runner(emu_lib, m, N).run_const(ub[:, :, :2], ub[:, 0, :], (1, 2, 3))
+    with pytest.raises(DimensionMismatch):
+        emu_runner(emu_lib, m, N).run_const(ub[:, :, :1], ub[:, 0, :3], (1, 2, 3))
+
+
 def element_parameter_sweeps():
     """(name, models, u[N, nu, T]): batches whose instances differ in ELEMENT parameters -- every model of the reference
     carries its own element closures (src/elements.jl:236-245, 309-406): a diode clipper swept over the diodes' saturation

@@ -958,6 +958,29 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
             assert np.abs(y - ylit).max() <= RTOL_SAME * scale
 
 
+def test_constant_input_rows(hip_lib):
+    """acme_batch_run_const on the GPU: the headline model with its three potentiometer rows handed over once per instance
+    -- host arrays (sliced pipeline: 9 000 samples) and device arrays -- gives the bits of run on the materialised input."""
+    import ctypes as C
+    import torch
+    from acme_jl_amd.model import CachingHomotopySolver
+    from acme_jl_amd.runner import ACME_MEM_DEVICE
+    m = load("superover_var", CachingHomotopySolver)
+    N, T = 70, 9000
+    ub = np.ascontiguousarray(sweep_inputs("superover_var", N, T, seed=3).transpose(0, 2, 1))
+    y_ref = runner(hip_lib, m, N).run(ub, time_major=True)
+    r = runner(hip_lib, m, N)
+    y = r.run_const(ub[:, :, :1], ub[:, 0, :], (1, 2, 3))
+    assert np.array_equal(y, y_ref)
+    rd = runner(hip_lib, m, N)
+    uv, uc = torch.from_numpy(np.ascontiguousarray(ub[:, :, :1])).cuda(), torch.from_numpy(np.ascontiguousarray(ub[:, 0, :])).cuda()
+    yd = torch.empty((N, T, m.ny), dtype=torch.float64, device="cuda")
+    rd.lib.check(rd.lib.L.acme_batch_run_const(rd.h, uv.data_ptr(), uc.data_ptr(), 0b1110, yd.data_ptr(), T, ACME_MEM_DEVICE,
+                                               torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y_ref)
+
+
 def test_streamed_host_path_only_when_the_grid_is_resident(hip_lib):
     """A streamed host-buffer run launches the kernel first and lets waves wait for their inputs to land (KArgs::u_ready);
     that is only safe while every block of the grid is resident.  A retained-array run of 516 blocks on a chip

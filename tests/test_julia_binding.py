@@ -74,7 +74,7 @@ def c_prototypes():
 
 # C type -> the Julia types that are a correct ccall spelling of it
 JULIA_FOR = {
-    "int": {"Cint"}, "long long": {"Clonglong"}, "double": {"Cdouble"},
+    "int": {"Cint"}, "long long": {"Clonglong"}, "unsigned long long": {"Culonglong"}, "double": {"Cdouble"},
     "const double*": {"Ptr{Cdouble}"}, "double*": {"Ptr{Cdouble}"},
     "const int*": {"Ptr{Cint}"}, "int*": {"Ptr{Cint}", "Ref{Cint}"},
     "float*": {"Ptr{Cfloat}", "Ref{Cfloat}"}, "long long*": {"Ptr{Clonglong}", "Ref{Clonglong}"},

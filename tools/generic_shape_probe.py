@@ -32,6 +32,10 @@ cases = [
     # the cooperative mid-size kernel's range (acme_coop.h; ACME_COOP=0: the lane-per-instance kernel)
     ("clipper chain, 12 stages (nn 24) [generic]", DiscreteModel(circuits.clipper_chain(12), t, CachingHomotopySolver, decompose_nonlinearity=False)),
     ("clipper chain, 16 stages (nn 32) [generic]", DiscreteModel(circuits.clipper_chain(16), t, CachingHomotopySolver, decompose_nonlinearity=False)),
+    # beyond the register instantiations: the any-size instantiation
+    ("clipper chain, 17 stages (nn 34) [generic]", DiscreteModel(circuits.clipper_chain(17), t, CachingHomotopySolver, decompose_nonlinearity=False)),
+    ("clipper chain, 24 stages (nn 48) [generic]", DiscreteModel(circuits.clipper_chain(24), t, CachingHomotopySolver, decompose_nonlinearity=False)),
+    ("clipper chain, 32 stages (nn 64) [generic]", DiscreteModel(circuits.clipper_chain(32), t, CachingHomotopySolver, decompose_nonlinearity=False)),
 ]
 if len(sys.argv) > 3:      # a subset by substring (underscores stand for blanks)
     sys.argv[3] = sys.argv[3].replace("_", " ")
