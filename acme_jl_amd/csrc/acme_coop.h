@@ -41,7 +41,8 @@ constexpr int COOP_SLOTS = COOP_MAX_N / GROUP;
 #ifdef ACME_DEV
 // -DACME_COOP_TIMING (tools/coop_timing_probe.py): shader-clock cycles per code region, per wave, written over y's first samples
 #ifdef ACME_COOP_TIMING
-enum { CT_SETP, CT_EXTRAP, CT_EVAL, CT_LU, CT_SOLVE, CT_ACCEPT, CT_LOOKUP, CT_XY, CT_PRE, CT_REST, CT_LU_SEARCH, CT_LU_HAND, CT_N };
+enum { CT_SETP, CT_EXTRAP, CT_EVAL, CT_LU, CT_SOLVE, CT_ACCEPT, CT_LOOKUP, CT_XY, CT_PRE, CT_REST, CT_LU_SEARCH, CT_LU_HAND,
+       CT_S_SCAN, CT_S_HEAD, CT_S_BAND, CT_S_REST, CT_S_CHUNKS, CT_S_STEPS, CT_N };
 struct CoopTimer { long long t[CT_N]; long long mark; };
 #define COOP_T(c, b) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)__builtin_readcyclecounter(); \
                           (c).tm->t[b] += t_ - (c).tm->mark; (c).tm->mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -57,7 +58,7 @@ struct CoopTimer { long long t[CT_N]; long long mark; };
 // 8.8 KB per instance at 20 unknowns instead of 15.9: 16 resident instances per compute unit instead of 8, a wave for
 // every SIMD.
 struct CoopOff {
-    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, total;
+    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, dinv, total;
 };
 ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
     CoopOff o{};
@@ -72,6 +73,36 @@ ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
     }
     const int nn = H.sub[0].nn, np = H.sub[0].np;
     int w = 0;
+    if (nc < 0) {
+        // the threshold path on ONE matrix in LDS (coop_lu_lds): row p = position p's Jacobian row, then its factors;
+        // column nn the right-hand side; the rows' 1 / pivot apart (a pair of columns is the unit of the elimination's
+        // reads and writes: the right-hand side's partner is slack).  Every array at an even offset (16-byte accesses).
+        auto take = [&](int n) { const int r = w; w += (n + 1) & ~1; return r; };
+        o.ld = ((nn + 3) & ~3) + 2;                  // (>= nn + 2, and 2 mod 4 doubles: the 16 rows of a DPP row in 16 bank groups)
+        o.llu = take(nn * o.ld);
+        o.xb = take(nn);                             // (behind the matrix: the replay's batched reads may run a few doubles past its last row)
+        o.dinv = take(nn);
+        o.tv = take(4 * nn);
+        o.ljp = take(nn * (np + 1));                 // (by residual ROW, whatever position holds it; behind the np columns one that stays
+                                                     // zero: where the padding entries of the rows' sparse forms point, GenSub::o_pcol)
+        o.lsrc = take(nn);
+        o.lp = take(np + 1);                         // (... and the p vectors' entry np stays zero likewise)
+        o.lz = take(nn);
+        o.x = take(H.nx);
+        o.xn = take(H.nx);
+        o.z = take(H.nnt);
+        o.p = take(H.npmax + 1);
+        o.pa = take(H.npmax + 1);
+        o.sp = take(H.npmax + 1);
+        o.zz = take(H.nnmax);
+        o.q = take(H.nqmax);
+        o.pf = take(H.nqmax);
+        o.tmp = take(H.nnmax);
+        o.u = take(H.nu);
+        o.res = o.dz = o.lu = o.src = o.prow = 0;
+        o.total = w;
+        return o;
+    }
     o.ld = nc + 2;                                   // (2 mod 4 doubles: the 16 rows of a DPP row in 16 bank groups)
     o.llu = w; w += nn * o.ld;                       // 16-byte aligned rows: offset and pitch even
     o.prow = w; w += nc + 2;                         // (the pivot row and, behind it, the position it came from)
@@ -120,8 +151,12 @@ ACME_HD inline int coop_table_doubles(const GenHeader &H) {
 }
 ACME_HD inline int coop_cache_doubles(const GenHeader &H) { return H.nsub > 0 ? ((H.sub[0].np * CACHE + 2 + 1) & ~1) : 0; }
 ACME_HD inline int coop_inst_doubles(const GenHeader &H, int nc) { return ((coop_offsets(H, nc).total + 1) & ~1) + coop_cache_doubles(H); }
-ACME_HD inline int coop_shared_doubles(const GenHeader &H, bool shared_image) {
-    return (shared_image ? ((H.image_total + 1) & ~1) : 0) + coop_table_doubles(H);
+// what a block stages of a shared model image: all of it -- or, for the instantiations on a matrix in LDS when the image has
+// its sparse forms (GenHeader::ell), only those: they read nothing else
+ACME_HD inline int coop_image_first(const GenHeader &H, int nc) { return nc < 0 && H.ell ? H.o_ell : 0; }
+ACME_HD inline int coop_image_doubles(const GenHeader &H, int nc) { return (H.image_total - coop_image_first(H, nc) + 1) & ~1; }
+ACME_HD inline int coop_shared_doubles(const GenHeader &H, bool shared_image, int nc) {
+    return (shared_image ? coop_image_doubles(H, nc) : 0) + coop_table_doubles(H);
 }
 ACME_DEV bool coop_any(const CoopCtx &c, bool x) { return ((wv::ballot(x) >> (c.grp * GROUP)) & 0xFFFFull) != 0ull; }
 
@@ -180,6 +215,24 @@ ACME_DEV double coop_dot_diff(const double *a, int sa, const double *b, const do
     return acc;
 }
 
+// acc + (row r of a matrix in its sparse form, GenEll) * x: the non-zeros in ascending column order -- the dense loop's
+// multiply-adds without the ones that add 0 * x_j
+ACME_DEV double coop_ell_dot(const double *M, const GenEll &E, int r, const double *x, double acc) {
+    for (int e = 0; e < E.k; e += 4) {
+        double v[4], xv[4];
+        int ci[4];
+        for (int u = 0; u < 4; ++u) {
+            const int ee = e + u < E.k ? e + u : E.k - 1;
+            v[u] = M[E.o_val + ee * E.rows + r];
+            ci[u] = (int)M[E.o_col + ee * E.rows + r];
+        }
+        for (int u = 0; u < 4; ++u) xv[u] = x[ci[u]];
+        for (int u = 0; u < 4; ++u)
+            if (e + u < E.k) acc = fma(v[u], xv[u], acc);
+    }
+    return acc;
+}
+
 // a row's descriptor out of the block's LDS copy of the tables (the constants beyond k[0..7], which only the rare element
 // kinds read, stay in HBM behind rd.rc)
 ACME_DEV void coop_rowdesc(const CoopCtx &c, int R, RowDesc &rd, int (&tc)[4]) {
@@ -196,7 +249,8 @@ ACME_DEV void coop_rowdesc(const CoopCtx &c, int R, RowDesc &rd, int (&tc)[4]) {
 // pfull <- q0 + pexp p  (set_p closure, src/ACME.jl:237-243); p at w_p must be visible (fenced)
 ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
     for (int r = c.lig; r < s.nq; r += GROUP) {
-        c.W[c.O.pf + r] = coop_dot(c.M + s.o_pexp + r, s.nq, c.W + w_p, s.np, c.M[s.o_q0 + r]);
+        c.W[c.O.pf + r] = c.H.ell ? coop_ell_dot(c.M, s.e_pexp, r, c.W + w_p, c.M[s.o_q0s + r])
+                                  : coop_dot(c.M + s.o_pexp + r, s.nq, c.W + w_p, s.np, c.M[s.o_q0 + r]);
     }
     wv::wave_fence();
 }
@@ -207,7 +261,8 @@ ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
 ACME_DEV bool coop_evaluate(const CoopCtx &c, const GenSub &s, int w_z, int o_lu) {
     const GenHeader &H = c.H;
     for (int r = c.lig; r < s.nq; r += GROUP) {
-        c.W[c.O.q + r] = coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
+        c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
+                                 : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
     bool bad = false;
@@ -434,7 +489,8 @@ ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, dou
     constexpr int NS = COOP_REG_SLOTS;
     const GenHeader &H = c.H;
     for (int r = c.lig; r < s.nq; r += GROUP) {
-        c.W[c.O.q + r] = coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
+        c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
+                                 : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
     bool bad = false;
@@ -737,9 +793,396 @@ template <int NC> ACME_DEV void coop_replay_gj(const CoopCtx &c, int n, int w_x)
     wv::wave_fence();
 }
 
+// ---- the THRESHOLD path on a matrix in LDS (everything the register instantiations do not take: up to 64 unknowns) ----
+// Beyond two rows per lane the Jacobian does not fit the registers (four rows of 64 columns are a wave's whole register
+// file), and the literal LU in LDS pays a search, an interchange and a division at every step and two triangular sweeps per
+// solve through LDS hand-offs (5.3e6 instance*samples/s at 34 unknowns).  Here the register instantiations' scheme -- the
+// instance's learnt row order, no search while every multiplier has |l| <= 8, v_rcp_f64 + refinement, the reference's
+// pivoting (coop_lu) only to learn a new order -- runs on ONE matrix per instance in LDS (instantiations NC = -NS, NS = the
+// slots in use: rows per lane), as an LU factorisation that looks at what the matrix holds:
+//   * position p (lane p mod 16, slot p / 16) owns row p of the matrix: evaluate! writes the Jacobian row of the residual
+//     row the order puts there (rid) and its residual (column n: the right-hand side rides along).  Step k reads the pivot
+//     row -- row k, whoever holds it: every lane of the instance reads the same addresses, an LDS broadcast -- and updates
+//     the rows BELOW in place, a PAIR of columns (16 bytes) per read and write; column k of such a row becomes minus its
+//     multiplier, 1 / pivot goes to a vector beside the matrix.  LU, not Gauss-Jordan as in registers: LDS stores are the
+//     expensive operation here (a 16-byte store costs a wave 13 cycles and more, a read 4), and eliminating above the pivot
+//     as well fills a banded matrix's upper triangle in.
+//   * a circuit's Jacobian is sparse, and x + l * 0 = x exactly: pairs of columns in which the pivot rows of ALL the wave's
+//     instances hold nothing are skipped, and so are the slots none of whose rows has a non-zero multiplier -- what remains
+//     is the dense elimination's arithmetic, bit for bit.  The four pairs next to the pivot's and the right-hand side's are
+//     read AHEAD of knowing what the pivot row holds (in a good order a circuit's entries sit near the diagonal), so a step
+//     that needs nothing else is one round trip through LDS.
+//   * the triangular sweeps keep x in registers and broadcast x_k by DPP (the step loop written out: compile-time lanes),
+//     the factors read in runs of eight columns.
+//   * the matrix an accepted iterate leaves behind IS the extrapolation origin's factorisation -- there is no second
+//     matrix and no copy: an instance whose solve ends without an accepted iterate, or that rode along without needing one
+//     (its matrix then holds some other linearisation), re-linearises at its origin before the origin is used again
+//     (CoopSolver::fresh: the `reorig` pass of coop_simple_solve, which the launch start and solution-cache hits use anyway).
+//     Half the LDS of the literal path: twice the resident instances.
+template <int NS, int NP>
+ACME_DEV void coop_lu_lds_chunk(double *const (&row)[NS], const bool (&act)[NS], bool real_last, const double *prow, const double (&m)[NS], int col) {
+    wv::pair_t b[NP], a[NS][NP];
+    sfor<0, NP>([&](auto uc) ACME_LAMBDA { constexpr int u = decltype(uc)::value; b[u] = wv::ld2(prow + col + 2 * u); });
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        if (act[sl])
+            sfor<0, NP>([&](auto uc) ACME_LAMBDA { constexpr int u = decltype(uc)::value; a[sl][u] = wv::ld2(row[sl] + col + 2 * u); });
+    });
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        if (act[sl] && (sl < NS - 1 || real_last))          // (only the last slot in use can hold positions beyond the matrix)
+            sfor<0, NP>([&](auto uc) ACME_LAMBDA {
+                constexpr int u = decltype(uc)::value;
+                wv::st2(row[sl] + col + 2 * u, fma(m[sl], b[u].lo, a[sl][u].lo), fma(m[sl], b[u].hi, a[sl][u].hi));
+            });
+    });
+}
+// One step of the factorisation (ODD: k is odd -- column k is the upper half of its pair).  vmx: the lane's largest |multiplier|.
+template <int NS, bool ODD>
+ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
+    double *F = c.W + c.O.llu;
+    const int ld = c.O.ld, kc = k & ~1;                   // (kc: the pair holding column k)
+    const int ks = k / GROUP;                             // (the slots below ks hold rows above the pivot: not touched)
+    const double *prow = F + k * ld;
+    const wv::pair_t pp = wv::ld2(prow + kc);
+    double *row[NS];
+    wv::pair_t own[NS];
+    const bool real_last = c.lig + GROUP * (NS - 1) < n;
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int p = c.lig + GROUP * sl;
+        row[sl] = F + ((sl < NS - 1 || real_last) ? p : n - 1) * ld;          // (a position beyond the matrix reads its last row, writes nothing)
+        own[sl] = wv::pair_t{0.0, 0.0};
+        if (sl >= ks) own[sl] = wv::ld2(row[sl] + kc);
+    });
+    // which of the pairs right of the pivot's hold anything in the pivot row -- of ANY of the wave's instances: lane l looks
+    // at pairs l, l + 16 (, l + 32 beyond 62 columns: the right-hand side's pair of a 64-unknown system)
+    const int g0 = kc / 2 + 1, g1 = n / 2;                // first and last pair of the update (g1: the right-hand side's)
+    unsigned nzmask[3];
+    sfor<0, 3>([&](auto hc) ACME_LAMBDA {
+        constexpr int h = decltype(hc)::value;
+        nzmask[h] = 0u;
+        if (h < 2 || g1 >= 32) {
+            const int g = c.lig + GROUP * h;
+            const bool in = g >= g0 && g <= g1;
+            const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
+            const unsigned long long bal = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));          // (a NaN counts as something)
+            nzmask[h] = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+        }
+    });
+    // read ahead: the four pairs next to the pivot's and the right-hand side's, of the pivot row and of the rows below
+    constexpr int NB = 4;
+    wv::pair_t bb[NB + 1], ab[NS][NB + 1];
+    int gb[NB + 1];
+    sfor<0, NB + 1>([&](auto uc) ACME_LAMBDA {
+        constexpr int u = decltype(uc)::value;
+        const int g = u < NB ? g0 + u : g1;
+        gb[u] = g <= g1 ? g : g1;          // (beyond the row: the right-hand side's pair once more -- read, not written)
+        bb[u] = wv::ld2(prow + 2 * gb[u]);
+        sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+            constexpr int sl = decltype(sc)::value;
+            if (sl >= ks) ab[sl][u] = wv::ld2(row[sl] + 2 * gb[u]);
+        });
+    });
+    COOP_T(c, CT_S_SCAN);
+    const double piv = ODD ? pp.hi : pp.lo;
+    const double inv = wv::recip(piv);
+    double m[NS];
+    bool act[NS];
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int p = c.lig + GROUP * sl;
+        const bool below = sl >= ks && p > k;
+        const double a = ODD ? own[sl].hi : own[sl].lo;
+        m[sl] = below ? -a * inv : 0.0;
+        vmx = fmax(vmx, fabs(m[sl]));
+        act[sl] = sl >= ks && wv::ballot(m[sl] != 0.0) != 0ull;          // (a slot none of whose rows -- in any instance -- changes)
+        if (act[sl] && (sl < NS - 1 || real_last)) {
+            // column k of the rows below: minus the multiplier; the rows above (and the pivot's) keep what they hold
+            if (ODD) wv::st2(row[sl] + kc, own[sl].lo, below ? m[sl] : own[sl].hi);
+            else wv::st2(row[sl] + kc, below ? m[sl] : own[sl].lo, fma(m[sl], pp.hi, own[sl].hi));
+        }
+    });
+    if (c.lig == (k & (GROUP - 1))) c.W[c.O.dinv + k] = inv;
+    const unsigned long long todo = (unsigned long long)nzmask[0] | ((unsigned long long)nzmask[1] << 16) | ((unsigned long long)nzmask[2] << 32);
+    COOP_T(c, CT_S_HEAD);
+    // the pairs read ahead (the right-hand side's always -- on its own where it is not one of the four)
+    sfor<0, NB + 1>([&](auto uc) ACME_LAMBDA {
+        constexpr int u = decltype(uc)::value;
+        const bool due = u < NB ? (g0 + u <= g1 && (((todo >> (g0 + u)) & 1ull) != 0ull || g0 + u == g1)) : g0 + NB <= g1;
+        if (due)
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                if (act[sl] && (sl < NS - 1 || real_last))
+                    wv::st2(row[sl] + 2 * gb[u], fma(m[sl], bb[u].lo, ab[sl][u].lo), fma(m[sl], bb[u].hi, ab[sl][u].hi));
+            });
+    });
+    // what the pivot row holds beyond them: four pairs at a time where any of the four holds something, single pairs at the
+    // row's end (short of the right-hand side's pair: that one is done)
+    COOP_T(c, CT_S_BAND);
+    int g = g0 + NB;
+    for (; g + 4 <= g1; g += 4)
+        if ((todo >> g) & 0xFull) {
+            coop_lu_lds_chunk<NS, 4>(row, act, real_last, prow, m, 2 * g);
+#ifdef ACME_COOP_TIMING
+            c.tm->t[CT_S_CHUNKS] += 1;
+#endif
+        }
+    for (; g < g1; ++g)
+        if ((todo >> g) & 1ull) {
+            coop_lu_lds_chunk<NS, 1>(row, act, real_last, prow, m, 2 * g);
+#ifdef ACME_COOP_TIMING
+            c.tm->t[CT_S_CHUNKS] += 1;
+#endif
+        }
+#ifdef ACME_COOP_TIMING
+    c.tm->t[CT_S_STEPS] += 1;
+#endif
+    COOP_T(c, CT_S_REST);
+}
+// The triangular sweeps on x in registers (slot sl of the lane: position lig + 16 sl), the factors read from the lane's rows
+// in runs of eight columns, x_k broadcast by DPP.
+//   forward:  x_p += l_pk x_k  for p > k  (l: minus the multiplier, as stored), k ascending
+template <int NS> ACME_DEV void coop_lds_forward(int lig, int n, double (&x)[NS], const double *const (&row)[NS]) {
+    sfor<0, 2 * NS>([&](auto gc) ACME_LAMBDA {
+        constexpr int k0 = 8 * decltype(gc)::value, ks = k0 / GROUP;
+        if (k0 < n) {
+            double m[NS][8];
+            sfor<ks, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                sfor<0, 4>([&](auto uc) ACME_LAMBDA {
+                    constexpr int u = decltype(uc)::value;
+                    const wv::pair_t v = wv::ld2(row[sl] + k0 + 2 * u);
+                    m[sl][2 * u] = v.lo;
+                    m[sl][2 * u + 1] = v.hi;
+                });
+            });
+            sfor<0, 8>([&](auto uc) ACME_LAMBDA {
+                constexpr int u = decltype(uc)::value, k = k0 + u, kl = k % GROUP;
+                if (k0 + 8 <= n || k < n) {          // (whole runs are inside the model for all but the last)
+                    const double xk = wv::bcast16_ordered<kl, true>(x[ks]);
+                    x[ks] = lig > kl ? fma(m[ks][u], xk, x[ks]) : x[ks];
+                    sfor<ks + 1, NS>([&](auto sc) ACME_LAMBDA { constexpr int sl = decltype(sc)::value; x[sl] = fma(m[sl][u], xk, x[sl]); });
+                }
+            });
+        }
+    });
+}
+//   backward: x_k <- x_k / u_kk,  x_p -= u_pk x_k  for p < k,  k descending (the division: times the stored 1 / pivot; the
+//   lanes' own x_p are scaled at the end, all at once -- x_p is not touched after its own step)
+template <int NS> ACME_DEV void coop_lds_backward(int lig, int n, double (&x)[NS], const double *const (&row)[NS], const double (&dinv)[NS]) {
+    sfor_down<2 * NS>([&](auto gc) ACME_LAMBDA {
+        constexpr int k0 = 8 * decltype(gc)::value, ks = k0 / GROUP;
+        if (k0 < n) {
+            double m[NS][8];
+            sfor<0, ks + 1>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                sfor<0, 4>([&](auto uc) ACME_LAMBDA {
+                    constexpr int u = decltype(uc)::value;
+                    const wv::pair_t v = wv::ld2(row[sl] + k0 + 2 * u);
+                    m[sl][2 * u] = v.lo;
+                    m[sl][2 * u + 1] = v.hi;
+                });
+            });
+            sfor_down<8>([&](auto uc) ACME_LAMBDA {
+                constexpr int u = decltype(uc)::value, k = k0 + u, kl = k % GROUP;
+                if (k0 + 8 <= n || k < n) {
+                    const double xk = wv::bcast16_ordered<kl, true>(x[ks] * dinv[ks]);
+                    x[ks] = lig < kl ? fma(-m[ks][u], xk, x[ks]) : x[ks];
+                    sfor<0, ks>([&](auto sc) ACME_LAMBDA { constexpr int sl = decltype(sc)::value; x[sl] = fma(-m[sl][u], xk, x[sl]); });
+                }
+            });
+        }
+    });
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA { constexpr int sl = decltype(sc)::value; x[sl] *= dinv[sl]; });
+}
+// [J | res] of the matrix at O.llu -> its factorisation, x = J^-1 res (unknown p at position p).  Returns (per lane)
+// whether its instance must not trust the result: threshold tripped, zero or non-finite pivot.
+template <int NS>
+ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS]) {
+    double vmx = 0.0;
+    for (int k = 0; k < n; k += 2) {
+        coop_lu_lds_step<NS, false>(c, n, k, vmx);
+        wv::lds_order();          // (a step reads what the step before wrote: the DS pipeline keeps a wave's program order)
+        if (k + 1 < n) {
+            coop_lu_lds_step<NS, true>(c, n, k + 1, vmx);
+            wv::lds_order();
+        }
+    }
+#ifdef ACME_COOP_TIMING
+    COOP_T(c, CT_LU_SEARCH);          // (developer timing: what the steps' own regions leave; the sweep under "setlhs!"; calls counted in the next slot)
+    c.tm->t[CT_LU_HAND] += 1;
+#endif
+    const double *F = c.W + c.O.llu;
+    const double *row[NS];
+    double dinv[NS];
+    bool real[NS];
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int p = c.lig + GROUP * sl;
+        real[sl] = p < n;
+        row[sl] = F + (real[sl] ? p : n - 1) * c.O.ld;
+        dinv[sl] = c.W[c.O.dinv + (real[sl] ? p : 0)];
+        x[sl] = real[sl] ? row[sl][n] : 0.0;          // (the right-hand side came through the forward sweep as a column)
+    });
+    coop_lds_backward<NS>(c.lig, n, x, row, dinv);
+    bool trip = vmx > COOP_PIVOT_THRESHOLD;
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        trip = trip || (real[sl] && (!(x[sl] * 0.0 == 0.0) || dinv[sl] == 0.0));
+    });
+    return coop_any(c, trip);
+}
+
+// evaluate!(nleq, z) as coop_evaluate, in the instance's row order: position p's row of the matrix <- the Jacobian row of
+// residual row rid (columns 0 .. nn - 1) and that residual (column nn); the rows' Jq non-zeros to O.tv by position
+template <int NS>
+ACME_DEV bool coop_evaluate_lds(const CoopCtx &c, const GenSub &s, int w_z, const int (&rid)[COOP_SLOTS], double (&res)[NS]) {
+    const GenHeader &H = c.H;
+    double *F = c.W + c.O.llu;
+    for (int r = c.lig; r < s.nq; r += GROUP) {
+        c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
+                                 : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
+    }
+    wv::wave_fence();
+    bool bad = false;
+    const wv::ExpTab etab = wv::load_exp_tab();
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int r = rid[sl], p = c.lig + GROUP * sl;
+        res[sl] = 0.0;
+        if (r >= 0) {
+            RowDesc rd;
+            int tc[4];
+            coop_rowdesc(c, s.row0 + r, rd, tc);
+            double e[4], tv[4], rs;
+            for (int t = 0; t < 4; ++t) e[t] = c.W[c.O.q + tc[t]];
+            const bool expo = rd.kind == RK_DIODE || rd.kind == RK_BJT;
+            const double exA = exp_junction(expo ? e[0] * rd.k[0] : 0.0, etab);
+            const double exB = H.has_bjt ? exp_junction(rd.kind == RK_BJT ? e[1] * rd.k[1] : 0.0, etab) : 1.0;
+            eval_row<true, 4>(rd, e, exA, exB, rs, tv);
+            res[sl] = rs;
+            bad = bad || !(rs * 0.0 == 0.0);
+            wv::st2(c.W + c.O.tv + 4 * p, tv[0], tv[1]);
+            wv::st2(c.W + c.O.tv + 4 * p + 2, tv[2], tv[3]);
+            double *row = F + p * c.O.ld;
+            if (H.ell) {
+                // J row = Jq row * fq from the row's sparse form (GenSub::o_jcol): zeros, then the columns that hold anything
+                for (int j = 0; j < c.O.ld; j += 2) wv::st2(row + j, 0.0, 0.0);
+                for (int e = 0; e < s.kj; e += 4) {
+                    int col[4];
+                    double cf[4][4];
+                    for (int u = 0; u < 4; ++u) {
+                        const int ee = e + u < s.kj ? e + u : s.kj - 1;
+                        col[u] = (int)c.M[s.o_jcol + ee * s.nn + r];
+                        for (int t = 0; t < 4; ++t) cf[u][t] = c.M[s.o_jcoef + (ee * 4 + t) * s.nn + r];
+                    }
+                    for (int u = 0; u < 4; ++u) {
+                        double acc = 0.0;
+                        for (int t = 0; t < 4; ++t) acc = fma(tv[t], cf[u][t], acc);
+                        bad = bad || !(acc * 0.0 == 0.0);
+                        if (e + u < s.kj) row[col[u]] = acc;
+                    }
+                }
+            } else
+            for (int j = 0; j < s.nn; j += 4) {         // J row = Jq row * fq, four columns' operands at a time
+                double fv[4][4], acc[4];
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u < s.nn ? j + u : s.nn - 1;
+                    for (int t = 0; t < 4; ++t) fv[u][t] = c.M[s.o_fq + jj * s.nq + tc[t]];
+                }
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = 0.0;
+                    for (int t = 0; t < 4; ++t) acc[u] = fma(tv[t], fv[u][t], acc[u]);
+                    acc[u] = j + u < s.nn ? acc[u] : 0.0;
+                    bad = bad || !(acc[u] * 0.0 == 0.0);
+                }
+                wv::st2(row + j, acc[0], acc[1]);          // (the last group may reach into the row's slack: zeros)
+                wv::st2(row + j + 2, acc[2], acc[3]);
+            }
+            row[s.nn] = rs;                                // (after the zeros of the last group)
+        }
+    });
+    wv::wave_fence();
+    return bad;
+}
+
+// calc_Jp closure with the Jq non-zeros coop_evaluate_lds left (where `pred`): Jp is kept by residual ROW here -- the pattern
+// of a row's non-zeros is the model's, whatever position holds the row
+template <int NS>
+ACME_DEV void coop_calc_jp_lds(const CoopCtx &c, const GenSub &s, bool pred, const int (&rid)[COOP_SLOTS]) {
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int r = rid[sl], p = c.lig + GROUP * sl;
+        if (r >= 0) {
+            const int blk = (s.row0 + r) / GROUP, ln = (s.row0 + r) % GROUP;
+            int tc[4];
+            double tv[4];
+            for (int t = 0; t < 4; ++t) tc[t] = c.ti[blk * ROWI * GROUP + (3 + t) * GROUP + ln];
+            for (int t = 0; t < 4; ++t) tv[t] = c.W[c.O.tv + 4 * p + t];
+            if (c.H.ell) {
+                for (int e = 0; e < s.kp; e += 4) {
+                    int col[4];
+                    double cf[4][4];
+                    for (int u = 0; u < 4; ++u) {
+                        const int ee = e + u < s.kp ? e + u : s.kp - 1;
+                        col[u] = (int)c.M[s.o_pcol + ee * s.nn + r];
+                        for (int t = 0; t < 4; ++t) cf[u][t] = c.M[s.o_pcoef + (ee * 4 + t) * s.nn + r];
+                    }
+                    for (int u = 0; u < 4; ++u) {
+                        double acc = 0.0;
+                        for (int t = 0; t < 4; ++t) acc = fma(tv[t], cf[u][t], acc);
+                        if (pred && e + u < s.kp) c.W[c.O.ljp + col[u] * s.nn + r] = acc;
+                    }
+                }
+            } else
+            for (int j = 0; j < s.np; j += 4) {
+                double pv[4][4];
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u < s.np ? j + u : s.np - 1;
+                    for (int t = 0; t < 4; ++t) pv[u][t] = c.M[s.o_pexp + jj * s.nq + tc[t]];
+                }
+                for (int u = 0; u < 4; ++u) {
+                    double acc = 0.0;
+                    for (int t = 0; t < 4; ++t) acc = fma(tv[t], pv[u][t], acc);
+                    if (pred && j + u < s.np) c.W[c.O.ljp + (j + u) * s.nn + r] = acc;
+                }
+            }
+        }
+    });
+    wv::wave_fence();
+}
+
+// x <- A^-1 x with the factorisation in the matrix (x at w_x: entry p the right-hand side of the row at position p on the
+// way in, unknown p on the way out)
+template <int NS> ACME_DEV void coop_replay_lds(const CoopCtx &c, int n, int w_x) {
+    double *W = c.W;
+    const double *F = W + c.O.llu;
+    double x[NS], dinv[NS];
+    const double *row[NS];
+    bool real[NS];
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        const int p = c.lig + GROUP * sl;
+        real[sl] = p < n;
+        row[sl] = F + (real[sl] ? p : n - 1) * c.O.ld;
+        x[sl] = real[sl] ? W[w_x + p] : 0.0;
+        dinv[sl] = W[c.O.dinv + (real[sl] ? p : 0)];
+    });
+    coop_lds_forward<NS>(c.lig, n, x, row);
+    coop_lds_backward<NS>(c.lig, n, x, row, dinv);
+    wv::wave_fence();
+    sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+        constexpr int sl = decltype(sc)::value;
+        if (real[sl]) W[w_x + c.lig + GROUP * sl] = x[sl];
+    });
+    wv::wave_fence();
+}
+
 // the extrapolation's solve! of a kernel instantiated for NC columns (0: the LDS version, any size)
 template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
     if constexpr (NC > 0) coop_replay_gj<NC>(c, n, w_x);
+    else if constexpr (NC < 0) coop_replay_lds<-NC>(c, n, w_x);
     else coop_lu_solve(c, n, o_f, o_src, w_x);
 }
 
@@ -752,7 +1195,8 @@ struct CoopSolver {
     int rid[2];              // ... which rows of the sub-problem the lane's two slots hold (-1: none).  Literal path: slot
                              // sl's own row lig + 16 sl, for good; threshold path: the instance's learnt row order
     bool fresh;              // threshold path: the origin (lp, lz) has no recorded elimination yet (launch start): the next
-                             // solve linearises there first
+                             // solve linearises there first.  Matrix in LDS: ... or its one matrix holds something else by now
+    int rid4[COOP_SLOTS];    // threshold path on the matrix in LDS: the row each of the lane's (up to four) positions holds
 };
 ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
     const int a = f.o_lu, b = f.o_src;
@@ -829,6 +1273,61 @@ ACME_DEV void coop_linearize(const CoopCtx &c, const GenSub &s, CoopSolver &f, i
     }
 }
 
+// coop_linearize on the matrix in LDS: evaluate!(nleq, z at w_z) into the instance's one matrix, the elimination in place;
+// x = J^-1 res (unknown p at position p).  Learning a new order: the reference's pivoting on the same matrix (coop_lu: real
+// interchanges, the gather src[] says which of the present positions' rows ends where), adopted, and everything once more.
+template <int NS>
+ACME_DEV void coop_linearize_lds(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_z, bool act, double (&x)[NS], double &resmax, bool &ok) {
+    const int nn = s.nn;
+    int phase = 0;
+    bool learn = false;
+    ok = true;
+    for (;;) {
+        double res[NS];
+        const bool bad = coop_evaluate_lds<NS>(c, s, w_z, f.rid4, res);
+        COOP_T(c, CT_EVAL);
+        if (phase == 1) {
+            const bool okl = coop_lu(c, nn, c.O.llu, c.O.lsrc);
+            ok = learn ? okl : ok;
+            int *ob = reinterpret_cast<int *>(c.W + c.O.xb);
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                if (f.rid4[sl] >= 0) ob[c.lig + GROUP * sl] = f.rid4[sl];
+            });
+            wv::wave_fence();
+            sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+                constexpr int sl = decltype(sc)::value;
+                const int p = c.lig + GROUP * sl;
+                if (learn && p < nn) f.rid4[sl] = ob[(int)c.W[c.O.lsrc + p]];
+            });
+            wv::wave_fence();
+            COOP_T(c, CT_LU);
+            phase = 2;
+            continue;
+        }
+        const bool finite = !coop_any(c, bad);
+        double rm = 0.0;
+        sfor<0, NS>([&](auto sc) ACME_LAMBDA {
+            constexpr int sl = decltype(sc)::value;
+            const double v = fabs(res[sl]);
+            if (f.rid4[sl] >= 0 && v > rm) rm = v;
+        });
+        resmax = wv::allmax16(rm);
+        if (!finite) resmax = (double)NAN;
+        const bool trip = coop_lu_lds<NS>(c, nn, x);
+        COOP_T(c, CT_LU);
+        if (phase == 0) {
+            learn = act && finite && trip;
+            if (ACME_USUAL(wv::ballot(learn) == 0ull)) break;
+            ACME_DBG("coop relearn (LDS): instance %lld lane %d learn %d", c.i, c.lig, (int)learn);
+            phase = 1;
+            continue;
+        }
+        ok = ok && !(learn && trip);
+        break;
+    }
+}
+
 // set_extrapolation_origin(solver, p, z) (src/solvers.jl:183-196) at (w_lp, w_lz) for the instances with `pred` (the any-size
 // instantiation; the register instantiations re-linearise inside coop_simple_solve: `reorig`, one copy of the pass)
 ACME_DEV void coop_set_origin(const CoopCtx &c, const GenSub &s, CoopSolver &f, bool pred) {
@@ -854,7 +1353,32 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
     auto start = [&]() ACME_LAMBDA {
         coop_set_p(c, s, w_p);
         COOP_T(c, CT_SETP);
-        for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
+        if constexpr (NC < 0) {
+            // (Jp by residual row: position p takes the row it holds; from the row's sparse form where the image has it)
+            for (int sl = 0; sl < -NC; ++sl) {
+                const int r = f.rid4[sl];
+                if (r < 0) continue;
+                double acc = 0.0;
+                if (H.ell) {
+                    for (int e = 0; e < s.kp; e += 4) {
+                        double jv[4], dv[4];
+                        for (int u = 0; u < 4; ++u) {
+                            const int ee = e + u < s.kp ? e + u : s.kp - 1;
+                            const int col = (int)c.M[s.o_pcol + ee * nn + r];
+                            jv[u] = W[c.O.ljp + col * nn + r];
+                            dv[u] = W[w_p + col] - W[c.O.lp + col];
+                        }
+                        for (int u = 0; u < 4; ++u)
+                            if (e + u < s.kp) acc = fma(jv[u], dv[u], acc);
+                    }
+                } else {
+                    acc = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
+                }
+                W[c.O.tmp + c.lig + GROUP * sl] = acc;
+            }
+        } else {
+            for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
+        }
         wv::wave_fence();
         coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
         for (int r = c.lig; r < nn; r += GROUP)
@@ -865,9 +1389,8 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
     bool act = need, conv = false;
     double reslast = 0.0;
     its = 0;
-    if constexpr (NC > 0) {
-        constexpr int NS = COOP_REG_SLOTS;
-        const int wrow[NS] = {c.lig, c.lig + GROUP};
+    if constexpr (NC != 0) {
+        constexpr int NS = NC > 0 ? COOP_REG_SLOTS : -NC;
         int stage = wv::ballot(reorig) != 0ull ? 0 : 1;          // 0: re-linearising at the origin; 1: the start is due; 2: Newton
         for (;;) {
             if (stage == 0) {
@@ -881,9 +1404,11 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
                 its += act ? 1 : 0;
             }
             const bool origin = stage == 0;
-            double a[NS][NC], res[NS], tv[NS][4], dinv[NS], resmax;
+            constexpr int NCR = NC > 0 ? NC : 1;          // (the registers' arrays: not used by the instantiations on a matrix in LDS)
+            double a[COOP_REG_SLOTS][NCR], res[NS], tv[COOP_REG_SLOTS][4], dinv[COOP_REG_SLOTS], resmax;
             bool ok;
-            coop_linearize<NC>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, a, res, tv, dinv, resmax, ok);
+            if constexpr (NC > 0) coop_linearize<NC>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, a, res, tv, dinv, resmax, ok);
+            else coop_linearize_lds<NS>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, res, resmax, ok);
             const bool finite = resmax == resmax;
             const bool small = resmax < c.A.tol;
             const bool accept = !origin && act && finite && ok && small;
@@ -900,8 +1425,13 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             // is being re-linearised keeps its p and z
             const bool rec = origin ? reorig : accept;
             if (wv::ballot(rec) != 0ull) {
-                coop_calc_jp_rows(c, s, tv, rec, f.rid, wrow);
-                coop_store_gj<NC>(c, nn, a, dinv, rec);
+                if constexpr (NC > 0) {
+                    const int wrow[COOP_REG_SLOTS] = {c.lig, c.lig + GROUP};
+                    coop_calc_jp_rows(c, s, tv, rec, f.rid, wrow);
+                    coop_store_gj<NC>(c, nn, a, dinv, rec);
+                } else {
+                    coop_calc_jp_lds<NS>(c, s, rec, f.rid4);          // (the matrix is the record already)
+                }
                 for (int j = c.lig; j < np; j += GROUP)
                     if (accept) W[c.O.lp + j] = W[w_p + j];
                 for (int r = c.lig; r < nn; r += GROUP)
@@ -916,6 +1446,8 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             conv = conv || accept;
             act = step && its < c.A.maxiter;
         }
+        // matrix in LDS: it is the origin's recorded elimination only where this solve ended with an accepted iterate
+        if constexpr (NC < 0) f.fresh = !(need && conv);
     } else {
         start();
         while (wv::ballot(act) != 0ull) {
@@ -970,8 +1502,10 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
     int *meta = reinterpret_cast<int *>(cp + np * CACHE);
     double *cz = c.A.cache + (c.valid ? c.i : 0) * c.H.cache_total + s.c_off + np * CACHE + 2;   // the stored z's: HBM
     const bool caching = c.A.solver == SOLVER_CACHING_HOMOTOPY;
-    bool reorig = f.fresh;          // (threshold path: the origin still lacks its recorded elimination at launch start)
-    f.fresh = false;
+    // (threshold path: the origin still lacks its recorded elimination -- launch start; matrix in LDS: or has lost it,
+    // which matters once the instance needs a solve again)
+    bool reorig = NC < 0 ? f.fresh && need : f.fresh;
+    f.fresh = NC < 0 ? f.fresh && !need : false;
     if (caching) {
         static_assert(CACHE == GROUP, "one stored solution per lane");
         double best = 0.0, d = 0.0;
@@ -995,7 +1529,7 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
             for (int r = c.lig; r < nn; r += GROUP)
                 if (hit) W[c.O.lz + r] = cz[e * nn + r];
             wv::wave_fence();
-            if constexpr (NC > 0) reorig = reorig || hit;          // (a pass of coop_simple_solve's loop)
+            if constexpr (NC != 0) reorig = reorig || hit;         // (a pass of coop_simple_solve's loop)
             else coop_set_origin(c, s, f, hit);
         }
     }
@@ -1082,12 +1616,13 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));
     // ---- the block's shared part: model image (if shared) and row tables, loaded by all its lanes ----
     double *img = lds;
-    double *tk = lds + (IMGL ? ((H.image_total + 1) & ~1) : 0);
+    const int img0 = coop_image_first(H, NC);          // (the part of the image this instantiation reads)
+    double *tk = lds + (IMGL ? coop_image_doubles(H, NC) : 0);
     const int blocks = (H.nnt + GROUP - 1) / GROUP;
     int *ti = reinterpret_cast<int *>(tk + blocks * 8 * GROUP);
     const int t0 = wave_in_block * 64 + lane, tstep = wpb * 64;
     if constexpr (IMGL)
-        for (int k = t0; k < H.image_total; k += tstep) img[k] = A.image[k];
+        for (int k = t0; k < H.image_total - img0; k += tstep) img[k] = A.image[img0 + k];
     for (int k = t0; k < blocks * 8 * GROUP; k += tstep) {
         const int blk = k / (8 * GROUP), rest = k % (8 * GROUP);
         tk[k] = A.rowc[(long long)blk * ROWC * GROUP + rest];       // constants 0 .. 7 of the block's 16 rows
@@ -1112,9 +1647,9 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     const bool valid = true;
     const long long i = wr ? slot : (long long)wave_global * gpw;
     const CoopOff O = coop_offsets(H, NC);
-    double *W = lds + coop_shared_doubles(H, IMGL) + (long long)(wave_in_block * gpw + (wr ? grp : 0)) * coop_inst_doubles(H, NC);
+    double *W = lds + coop_shared_doubles(H, IMGL, NC) + (long long)(wave_in_block * gpw + (wr ? grp : 0)) * coop_inst_doubles(H, NC);
     double *Cp = W + ((O.total + 1) & ~1);
-    CoopCtx c{A, H, O, IMGL ? img : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid, wr};
+    CoopCtx c{A, H, O, IMGL ? img - img0 : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid, wr};
 #ifdef ACME_COOP_TIMING
     CoopTimer tmr{};
     tmr.mark = (long long)__builtin_readcyclecounter();
@@ -1124,13 +1659,18 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     long long *rep = A.report + i * RW_WORDS;
     const bool has_sub = H.nsub > 0;
     const GenSub &s = H.sub[0];
-    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}, {-1, -1}, NC > 0};
+    CoopSolver f{c.O.lu, c.O.src, has_sub ? c.O.llu : 0, has_sub ? c.O.lsrc : 0, {-1, -1}, {-1, -1}, NC != 0, {-1, -1, -1, -1}};
     // the rows the lane's two slots hold: what the instance's order -- learnt in earlier launches, GArgs::coop_order -- puts
     // at the slots' positions
     if constexpr (NC > 0)
         for (int sl = 0; sl < 2; ++sl) {
             const int p = lig + GROUP * sl;
-            f.rid[sl] = (has_sub && p < s.nn) ? A.coop_order[i * (2 * GROUP) + p] : -1;
+            f.rid[sl] = (has_sub && p < s.nn) ? A.coop_order[i * COOP_MAX_N + p] : -1;
+        }
+    if constexpr (NC < 0)
+        for (int sl = 0; sl < -NC; ++sl) {
+            const int p = lig + GROUP * sl;
+            f.rid4[sl] = (has_sub && p < s.nn) ? A.coop_order[i * COOP_MAX_N + p] : -1;
         }
     const bool caching = has_sub && A.solver == SOLVER_CACHING_HOMOTOPY;
     double *cache_g = A.cache + i * H.cache_total + (has_sub ? s.c_off : 0);
@@ -1173,8 +1713,14 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         if (has_sub) {
             // p = dq x + eq u  (src/ACME.jl:678-683; a first sub-problem has no fqprev term)
             for (int r = lig; r < s.np; r += GROUP) {
-                double acc = coop_dot(c.M + s.o_dq + r, s.np, W + c.O.x, H.nx, 0.0);
-                acc = coop_dot(c.M + s.o_eq + r, s.np, un, H.nu, acc);
+                double acc;
+                if (H.ell) {
+                    acc = coop_ell_dot(c.M, s.e_dq, r, W + c.O.x, 0.0);
+                    acc = coop_ell_dot(c.M, s.e_eq, r, un, acc);
+                } else {
+                    acc = coop_dot(c.M + s.o_dq + r, s.np, W + c.O.x, H.nx, 0.0);
+                    acc = coop_dot(c.M + s.o_eq + r, s.np, un, H.nu, acc);
+                }
                 if (alive) W[c.O.p + r] = acc;
             }
             wv::wave_fence();
@@ -1211,9 +1757,16 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         for (int rho = lig; rho < H.nx + H.ny; rho += GROUP) {
             const bool isx = rho < H.nx;
             const int r = isx ? rho : rho - H.nx, ldm = isx ? H.nx : H.ny;
-            double acc = coop_dot(c.M + (isx ? H.o_a : H.o_dy) + r, ldm, W + c.O.x, H.nx, c.M[(isx ? H.o_x0 : H.o_y0) + r]);
-            acc = coop_dot(c.M + (isx ? H.o_b : H.o_ey) + r, ldm, un, H.nu, acc);
-            acc = coop_dot(c.M + (isx ? H.o_c : H.o_fy) + r, ldm, W + c.O.z, H.nnt, acc);
+            double acc;
+            if (H.ell) {
+                acc = coop_ell_dot(c.M, H.e_ax, rho, W + c.O.x, c.M[H.o_xy0 + rho]);
+                acc = coop_ell_dot(c.M, H.e_bu, rho, un, acc);
+                acc = coop_ell_dot(c.M, H.e_cz, rho, W + c.O.z, acc);
+            } else {
+                acc = coop_dot(c.M + (isx ? H.o_a : H.o_dy) + r, ldm, W + c.O.x, H.nx, c.M[(isx ? H.o_x0 : H.o_y0) + r]);
+                acc = coop_dot(c.M + (isx ? H.o_b : H.o_ey) + r, ldm, un, H.nu, acc);
+                acc = coop_dot(c.M + (isx ? H.o_c : H.o_fy) + r, ldm, W + c.O.z, H.nnt, acc);
+            }
             if (isx) {
                 if (live) W[c.O.xn + r] = acc;
             } else {
@@ -1239,7 +1792,10 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             for (int k = lig; k < s.np * CACHE + 2; k += GROUP) cache_g[k] = Cp[k];
         if constexpr (NC > 0)          // (a run split over several launches repeats the one-launch arithmetic)
             for (int sl = 0; sl < 2; ++sl)
-                if (lig + GROUP * sl < s.nn) A.coop_order[i * (2 * GROUP) + lig + GROUP * sl] = f.rid[sl];
+                if (lig + GROUP * sl < s.nn) A.coop_order[i * COOP_MAX_N + lig + GROUP * sl] = f.rid[sl];
+        if constexpr (NC < 0)
+            for (int sl = 0; sl < -NC; ++sl)
+                if (lig + GROUP * sl < s.nn) A.coop_order[i * COOP_MAX_N + lig + GROUP * sl] = f.rid4[sl];
     }
     if (lig == 0 && wr) {
         rep[RW_ITERS_TOTAL] += it_total;

@@ -8,12 +8,12 @@
 
 // GArgs::coop_wpb waves per block, GArgs::coop_gpw instances per wave, their working arrays in LDS.
 //   NC:  17 ... 32 unknowns -- the Jacobian's rows in registers (NC columns), eliminated in the instance's learnt row order
-//        with threshold pivoting -- or 0: the reference's LU literally, factors in LDS, any size (ACME_COOP_LITERAL=1 /
-//        ACME_COOP_REG=0 select it for 17 ... 32 unknowns as well)
+//        with threshold pivoting; -1 ... -4: the same elimination on one matrix in LDS, that many rows per lane (up to 64
+//        unknowns); 0: the reference's LU literally, factors in LDS, any size (ACME_COOP_LITERAL=1)
 // The any-size instantiation is held to 256 registers -- no accumulation registers (__graft_entry__.py checks the code
 // object) --, two waves per SIMD; the register instantiations take what one wave per SIMD may have.  DESIGN.md 3 "The zeros
 // of the unbounded any-size build" has the story of that bound.
-template <bool IMGL, int NC> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 0 ? 2 : 1)))
+template <bool IMGL, int NC> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC <= 0 ? 2 : 1)))
 void acme_coop_kernel(acme::GArgs A) {
     extern __shared__ double acme_lds[];
     const int wave = (int)threadIdx.x >> 6;
@@ -26,6 +26,10 @@ const void *acme_coop_fn_nc20(int imgl);
 const void *acme_coop_fn_nc24(int imgl);
 const void *acme_coop_fn_nc28(int imgl);
 const void *acme_coop_fn_nc32(int imgl);
+const void *acme_coop_fn_lds1(int imgl);          // (the threshold path on a matrix in LDS, 1 ... 4 rows per lane: NC = -1 ... -4)
+const void *acme_coop_fn_lds2(int imgl);
+const void *acme_coop_fn_lds3(int imgl);
+const void *acme_coop_fn_lds4(int imgl);
 template <int NC> static inline const void *coop_fns_of(int imgl) {
     return imgl ? (const void *)acme_coop_kernel<true, NC> : (const void *)acme_coop_kernel<false, NC>;
 }

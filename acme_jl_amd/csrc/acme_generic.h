@@ -20,6 +20,12 @@ namespace acme {
 
 constexpr int GEN_MAX_SUB = 64;
 
+// The non-zeros of a matrix, row by row, for the mid-size kernel (acme_coop.h): entry e of row r at [e * rows + r] of the
+// values and of the column numbers (kept as doubles), k entries per row -- the fullest row's count; rows with fewer end in
+// (0.0, column 0).  A circuit's matrices are sparse (the 34-unknown clipper chain: 1.75 non-zeros per row of fq), a dense
+// matrix-vector product reads mostly zeros -- from L2, when the image does not fit the LDS.  Taken in ascending column
+// order the products that remain are the dense loop's, bit for bit: x + 0 * y = x.
+struct GenEll { int o_val, o_col, k, rows; };
 // one nonlinear sub-problem: dimensions, where its matrices sit in the model image (column-major, as the caller
 // handed them over), its rows in the row tables, its slices of the per-instance arrays
 struct GenSub {
@@ -30,11 +36,24 @@ struct GenSub {
     int row0;                // first of its rows in the row tables (global row R: block R / 16, lane R % 16)
     int w_lp, w_lz, w_ljp, w_llu, w_lpiv;              // workspace: the extrapolation origin (p, z, Jp, LU, pivots)
     int c_off;               // its solution cache inside an instance's cache block
+    // sparse forms (GenHeader::ell; only built for a model with ONE sub-problem):
+    GenEll e_fq, e_pexp, e_dq, e_eq;
+    int o_q0s;               // q0 once more, inside the sparse part of the image
+    // J = Jq fq row by row: residual row r's columns with anything in them -- entry e: column jcol[e * nn + r] (padding: the
+    // slack column nn + 1) and, for each of the row's four Jq terms t, fq[tc[t]][column] at jcoef[(e * 4 + t) * nn + r]
+    int o_jcol, o_jcoef, kj;
+    // Jp = Jq pexp likewise (padding: column np, a column of zeros the mid-size kernel keeps behind its Jp)
+    int o_pcol, o_pcoef, kp;
 };
 struct GenHeader {
     int nx, nu, ny, nsub, nnt, npt;
     int o_a, o_b, o_c, o_x0, o_dy, o_ey, o_fy, o_y0;
     int image_total;
+    int ell;                 // the sparse forms below and in sub[0] exist and hold every non-zero of this model (a batch: of every
+                             // instance's model) -- the mid-size kernel reads them instead of the dense matrices
+    int o_ell;               // where the sparse part of the image begins (an even offset; image_total if there is none)
+    GenEll e_ax, e_bu, e_cz; // [a; dy], [b; ey], [c; fy]: the nx state rows followed by the ny output rows
+    int o_xy0;               // x0 followed by y0
     int nnmax, nqmax, npmax;
     int ldf;                 // leading dimension of the nnmax x nnmax factor matrices in the workspace (>= nnmax; the lane-per-instance
                              // kernel stores them column-major and packed, the cooperative one row-major with this row pitch)
@@ -73,10 +92,11 @@ struct GArgs {
     int coop_imgl;           // acme_coop.h: the (shared) model image is staged in LDS
     int coop_gpw;            // acme_coop.h: instances per wave (4, 2 or 1: what the LDS of a compute unit holds most of)
     int coop_wpb;            // acme_coop.h: waves per block (4, 2 or 1: they share one copy of the row tables / the image in LDS)
-    int coop_nc;             // acme_coop.h: the kernel instantiated for this many columns of the Jacobian in registers (20, 24, 28,
-                             // 32: 17 ... 32 unknowns rounded up to four; threshold pivoting in a learnt row order); 0: the any-size
-                             // kernel (the reference's LU, factors in LDS)
-    int *coop_order;         // [n_inst][32]: register instantiations, the row each position of an instance holds (kept between launches)
+    int coop_nc;             // acme_coop.h: the kernel's instantiation: 20, 24, 28, 32 -- that many columns of the Jacobian in registers
+                             // (17 ... 32 unknowns rounded up to four; threshold pivoting in a learnt row order); -1 ... -4: the same
+                             // elimination on one matrix in LDS, that many rows per lane; 0: the any-size kernel (the reference's LU
+                             // literally, factors in LDS)
+    int *coop_order;         // [n_inst][64]: threshold path, the row each position of an instance holds (kept between launches)
 };
 
 #ifdef ACME_DEV

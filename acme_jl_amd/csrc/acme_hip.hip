@@ -169,6 +169,10 @@ static inline const void *coop_fn(const GArgs &A) {
     case 24: return acme_coop_fn_nc24(A.coop_imgl);
     case 28: return acme_coop_fn_nc28(A.coop_imgl);
     case 32: return acme_coop_fn_nc32(A.coop_imgl);
+    case -1: return acme_coop_fn_lds1(A.coop_imgl);
+    case -2: return acme_coop_fn_lds2(A.coop_imgl);
+    case -3: return acme_coop_fn_lds3(A.coop_imgl);
+    case -4: return acme_coop_fn_lds4(A.coop_imgl);
     default: return coop_fns_of<0>(A.coop_imgl);
     }
 }

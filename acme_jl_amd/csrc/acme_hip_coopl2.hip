@@ -1,0 +1,3 @@
+// mid-size kernel, threshold path on a matrix in LDS, 2 rows per lane: see acme_hip_coop.inc
+#define ACME_COOP_LDS_ROWS 2
+#include "acme_hip_coop.inc"

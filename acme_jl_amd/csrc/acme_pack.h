@@ -638,7 +638,10 @@ struct PackedGeneric {
     std::vector<double> image, rowc, init_state;
     std::vector<int> rowi;
 };
-inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err) {
+// like: the header of the batch this model is to join as ONE instance's model (acme_batch_set_matrices) -- its sparse forms
+// take the batch's entries per row, so that every instance's image has the batch's layout; a model with a fuller row than
+// that comes back with GenHeader::ell == 0 (the caller then runs the whole batch on the dense matrices).
+inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err, const GenHeader *like = nullptr) {
     GenHeader &H = G.H;
     H = GenHeader{};
     if ((int)m.subs.size() > GEN_MAX_SUB) {
@@ -707,6 +710,94 @@ inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err)
             if (!have[r]) { err = "a residual row belongs to no element"; return false; }
     }
     H.has_bjt = dummy.has_bjt;
+    // ---- the sparse forms of the matrices (the mid-size kernel, acme_coop.h: one sub-problem or none), behind the dense ones ----
+    H.ell = 0;
+    H.o_ell = H.image_total;
+    if (H.nsub <= 1) {
+        const int base = (H.image_total + 1) & ~1;
+        std::vector<double> tail;
+        bool fits = true;
+        auto at = [&]() { return base + (int)tail.size(); };
+        auto build = [&](GenEll &E, int nrows, int ncols, auto get, const GenEll *lk) {
+            int k = 0;
+            for (int r = 0; r < nrows; ++r) {
+                int cnt = 0;
+                for (int c = 0; c < ncols; ++c) cnt += get(r, c) != 0.0;
+                if (cnt > k) k = cnt;
+            }
+            if (lk) { if (k > lk->k) fits = false; k = lk->k; }
+            E.rows = nrows; E.k = k;
+            E.o_val = at(); tail.resize(tail.size() + (size_t)nrows * k, 0.0);
+            E.o_col = at(); tail.resize(tail.size() + (size_t)nrows * k, 0.0);
+            for (int r = 0; r < nrows; ++r) {
+                int e = 0;
+                for (int c = 0; c < ncols && e < k; ++c) {
+                    const double v = get(r, c);
+                    if (v != 0.0) {
+                        tail[E.o_val - base + (size_t)e * nrows + r] = v;
+                        tail[E.o_col - base + (size_t)e * nrows + r] = (double)c;
+                        ++e;
+                    }
+                }
+            }
+        };
+        const int nxy = m.nx + m.ny;
+        build(H.e_ax, nxy, m.nx, [&](int r, int c) { return r < m.nx ? m.a[(size_t)c * m.nx + r] : m.dy[(size_t)c * m.ny + (r - m.nx)]; }, like ? &like->e_ax : nullptr);
+        build(H.e_bu, nxy, m.nu, [&](int r, int c) { return r < m.nx ? m.b[(size_t)c * m.nx + r] : m.ey[(size_t)c * m.ny + (r - m.nx)]; }, like ? &like->e_bu : nullptr);
+        build(H.e_cz, nxy, nnt, [&](int r, int c) { return r < m.nx ? m.c[(size_t)c * m.nx + r] : m.fy[(size_t)c * m.ny + (r - m.nx)]; }, like ? &like->e_cz : nullptr);
+        H.o_xy0 = at();
+        tail.insert(tail.end(), m.x0.begin(), m.x0.end());
+        tail.insert(tail.end(), m.y0.begin(), m.y0.end());
+        if (H.nsub == 1) {
+            const HostSub &s = m.subs[0];
+            GenSub &g = H.sub[0];
+            const GenSub *lg = like ? &like->sub[0] : nullptr;
+            build(g.e_fq, s.nq, s.nn, [&](int r, int c) { return s.fq[(size_t)c * s.nq + r]; }, lg ? &lg->e_fq : nullptr);
+            build(g.e_pexp, s.nq, s.np, [&](int r, int c) { return s.pexp[(size_t)c * s.nq + r]; }, lg ? &lg->e_pexp : nullptr);
+            build(g.e_dq, s.np, m.nx, [&](int r, int c) { return s.dq[(size_t)c * s.np + r]; }, lg ? &lg->e_dq : nullptr);
+            build(g.e_eq, s.np, m.nu, [&](int r, int c) { return s.eq[(size_t)c * s.np + r]; }, lg ? &lg->e_eq : nullptr);
+            g.o_q0s = at();
+            tail.insert(tail.end(), s.q0.begin(), s.q0.end());
+            // the rows of J = Jq fq and Jp = Jq pexp: a residual row's four Jq terms sit at the q rows its table entry names
+            auto tc_of = [&](int r, int t) {
+                const int R = g.row0 + r;
+                return G.rowi[((size_t)(R / GROUP) * ROWI + 3 + t) * GROUP + R % GROUP];
+            };
+            auto rows_of = [&](const std::vector<double> &mat, int ncols, int pad_col, int like_k, int &k, int &o_col, int &o_coef) {
+                k = 0;
+                for (int r = 0; r < s.nn; ++r) {
+                    int cnt = 0;
+                    for (int c = 0; c < ncols; ++c) {
+                        bool any = false;
+                        for (int t = 0; t < 4; ++t) any = any || mat[(size_t)c * s.nq + tc_of(r, t)] != 0.0;
+                        cnt += any;
+                    }
+                    if (cnt > k) k = cnt;
+                }
+                if (like_k >= 0) { if (k > like_k) fits = false; k = like_k; }
+                o_col = at(); tail.resize(tail.size() + (size_t)s.nn * k, (double)pad_col);
+                o_coef = at(); tail.resize(tail.size() + (size_t)s.nn * k * 4, 0.0);
+                for (int r = 0; r < s.nn; ++r) {
+                    int e = 0;
+                    for (int c = 0; c < ncols && e < k; ++c) {
+                        bool any = false;
+                        for (int t = 0; t < 4; ++t) any = any || mat[(size_t)c * s.nq + tc_of(r, t)] != 0.0;
+                        if (!any) continue;
+                        tail[o_col - base + (size_t)e * s.nn + r] = (double)c;
+                        for (int t = 0; t < 4; ++t) tail[o_coef - base + ((size_t)e * 4 + t) * s.nn + r] = mat[(size_t)c * s.nq + tc_of(r, t)];
+                        ++e;
+                    }
+                }
+            };
+            rows_of(s.fq, s.nn, s.nn + 1, lg ? lg->kj : -1, g.kj, g.o_jcol, g.o_jcoef);
+            rows_of(s.pexp, s.np, s.np, lg ? lg->kp : -1, g.kp, g.o_pcol, g.o_pcoef);
+        }
+        H.o_ell = base;
+        H.ell = fits ? 1 : 0;
+        G.image.resize((size_t)base, 0.0);
+        G.image.insert(G.image.end(), tail.begin(), tail.end());
+        H.image_total = (int)G.image.size();
+    }
     // workspace
     // (factor matrices: room for the cooperative kernel's row pitch -- at least 3 columns of slack for its 4-wide updates,
     // and a pitch of 2 mod 4 doubles so that the 16 rows a DPP row of lanes touches in one LDS access fall into 16 distinct

@@ -270,6 +270,10 @@ static void coop_fiber_entry(void *p) {
     case 24: img ? coop_main<true, 24>(*c->A, lds, wave, wg, lane) : coop_main<false, 24>(*c->A, lds, wave, wg, lane); break;
     case 28: img ? coop_main<true, 28>(*c->A, lds, wave, wg, lane) : coop_main<false, 28>(*c->A, lds, wave, wg, lane); break;
     case 32: img ? coop_main<true, 32>(*c->A, lds, wave, wg, lane) : coop_main<false, 32>(*c->A, lds, wave, wg, lane); break;
+    case -1: img ? coop_main<true, -1>(*c->A, lds, wave, wg, lane) : coop_main<false, -1>(*c->A, lds, wave, wg, lane); break;
+    case -2: img ? coop_main<true, -2>(*c->A, lds, wave, wg, lane) : coop_main<false, -2>(*c->A, lds, wave, wg, lane); break;
+    case -3: img ? coop_main<true, -3>(*c->A, lds, wave, wg, lane) : coop_main<false, -3>(*c->A, lds, wave, wg, lane); break;
+    case -4: img ? coop_main<true, -4>(*c->A, lds, wave, wg, lane) : coop_main<false, -4>(*c->A, lds, wave, wg, lane); break;
     default: img ? coop_main<true, 0>(*c->A, lds, wave, wg, lane) : coop_main<false, 0>(*c->A, lds, wave, wg, lane); break;
     }
 }

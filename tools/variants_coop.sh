@@ -1,5 +1,5 @@
 #!/bin/bash
-# A build variant of the mid-size kernel only: recompiles acme_hip.hip and the acme_hip_coop<NC>.hip units with extra flags
+# A build variant of the mid-size kernel only: recompiles acme_hip.hip and the acme_hip_coop<NC>.hip / acme_hip_coopl<NS>.hip units with extra flags
 # and links them with the current objects of the other units (csrc/.obj) into build_variants/libacme_hip_<name>.so.
 #   usage: tools/variants_coop.sh <name> [hipcc flags]      e.g.  tools/variants_coop.sh nomirror -DACME_COOP_NO_MIRROR
 set -e
@@ -7,7 +7,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/acme_jl_amd/csrc; out=/tmp/variants_coop_$name
 mkdir -p $out $root/build_variants
-for u in acme_hip acme_hip_coop20 acme_hip_coop24 acme_hip_coop28 acme_hip_coop32; do
+for u in acme_hip acme_hip_coop20 acme_hip_coop24 acme_hip_coop28 acme_hip_coop32 acme_hip_coopl1 acme_hip_coopl2 acme_hip_coopl3 acme_hip_coopl4; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -join-splitedges=1 "$@" -c $src/$u.hip -o $out/$u.o 2> $out/$u.log &
 done
 wait
