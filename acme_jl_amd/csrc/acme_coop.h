@@ -37,6 +37,15 @@ namespace acme {
 
 constexpr int COOP_MAX_N = 64;      // unknowns / parameters of the sub-problem (4 rows per lane)
 constexpr int COOP_SLOTS = COOP_MAX_N / GROUP;
+// Instantiation codes (GArgs::coop_nc): > 0 columns of the Jacobian in registers; 0 the reference's LU literally; -1 ... -4 the
+// threshold path on a matrix in LDS with that many rows per lane, one instance per 16 lanes; COOP_WAVE64: the same with one
+// instance per WAVE, one row per lane -- a wave's time per sample is its instruction count whatever its lanes do (one wave
+// issues one instruction per four or five cycles), the instances resident per compute unit are what the LDS holds whatever
+// waves carry them, so beyond 32 unknowns (three or four rows per lane: every row operation three or four times in the
+// instruction stream) the row-per-lane layout is three to four times faster.
+constexpr int COOP_WAVE64 = -64;
+ACME_HD constexpr int coop_lpi(int nc) { return nc == COOP_WAVE64 ? 64 : GROUP; }
+ACME_HD constexpr int coop_ns(int nc) { return nc == COOP_WAVE64 ? 1 : nc < 0 ? -nc : 0; }
 
 #ifdef ACME_DEV
 // -DACME_COOP_TIMING (tools/coop_timing_probe.py): shader-clock cycles per code region, per wave, written over y's first samples
@@ -83,8 +92,9 @@ ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
         o.xb = take(nn);                             // (behind the matrix: the replay's batched reads may run a few doubles past its last row)
         o.dinv = take(nn);
         o.tv = take(4 * nn);
-        o.ljp = take(nn * (np + 1));                 // (by residual ROW, whatever position holds it; behind the np columns one that stays
-                                                     // zero: where the padding entries of the rows' sparse forms point, GenSub::o_pcol)
+        // Jp by residual ROW, whatever position holds it: np columns and one that stays zero (where the padding entries of the
+        // rows' sparse forms point, GenSub::o_pcol) -- or just the kp entries per row of the sparse form (GenHeader::jp_sparse)
+        o.ljp = take(H.ell && H.jp_sparse ? nn * H.sub[0].kp : nn * (np + 1));
         o.lsrc = take(nn);
         o.lp = take(np + 1);                         // (... and the p vectors' entry np stays zero likewise)
         o.lz = take(nn);
@@ -137,6 +147,7 @@ struct CoopCtx {
     const double *tk;        // the block's copy of the row tables in LDS: k[8] of every row ([blk][8][16]) ...
     const int *ti;           // ... and the rows' ints ([blk][ROWI][16])
     int lig, grp;
+    int lpi;                 // lanes per instance: 16 (one instance per DPP row) or 64 (COOP_WAVE64: one instance per wave)
     long long i;
     bool valid;
     bool wr;                 // this row of 16 lanes writes to global memory (false: it mirrors the wave's first row, coop_main)
@@ -158,7 +169,13 @@ ACME_HD inline int coop_image_doubles(const GenHeader &H, int nc) { return (H.im
 ACME_HD inline int coop_shared_doubles(const GenHeader &H, bool shared_image, int nc) {
     return (shared_image ? coop_image_doubles(H, nc) : 0) + coop_table_doubles(H);
 }
-ACME_DEV bool coop_any(const CoopCtx &c, bool x) { return ((wv::ballot(x) >> (c.grp * GROUP)) & 0xFFFFull) != 0ull; }
+ACME_DEV bool coop_any(const CoopCtx &c, bool x) {
+    const unsigned long long b = wv::ballot(x);
+    return c.lpi == 64 ? b != 0ull : ((b >> (c.grp * GROUP)) & 0xFFFFull) != 0ull;
+}
+// maximum / minimum over the lanes of an instance, in every one of them
+ACME_DEV double coop_allmax(const CoopCtx &c, double v) { return c.lpi == 64 ? wv::allmax64(v) : wv::allmax16(v); }
+ACME_DEV double coop_allmin(const CoopCtx &c, double v) { return c.lpi == 64 ? wv::allmin64(v) : wv::allmin16(v); }
 
 // Inner loops in BATCHES: a wave has nothing but its own instruction stream to hide a load's latency behind (LDS ~100
 // cycles, the model image in L2 several hundred), and the compiler may not move a load across the store of the iteration
@@ -248,7 +265,7 @@ ACME_DEV void coop_rowdesc(const CoopCtx &c, int R, RowDesc &rd, int (&tc)[4]) {
 
 // pfull <- q0 + pexp p  (set_p closure, src/ACME.jl:237-243); p at w_p must be visible (fenced)
 ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
-    for (int r = c.lig; r < s.nq; r += GROUP) {
+    for (int r = c.lig; r < s.nq; r += c.lpi) {
         c.W[c.O.pf + r] = c.H.ell ? coop_ell_dot(c.M, s.e_pexp, r, c.W + w_p, c.M[s.o_q0s + r])
                                   : coop_dot(c.M + s.o_pexp + r, s.nq, c.W + w_p, s.np, c.M[s.o_q0 + r]);
     }
@@ -260,14 +277,14 @@ ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
 // Returns (per lane) whether one of its residuals / Jacobian entries is not finite.
 ACME_DEV bool coop_evaluate(const CoopCtx &c, const GenSub &s, int w_z, int o_lu) {
     const GenHeader &H = c.H;
-    for (int r = c.lig; r < s.nq; r += GROUP) {
+    for (int r = c.lig; r < s.nq; r += c.lpi) {
         c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
                                  : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
     bool bad = false;
     const wv::ExpTab etab = wv::load_exp_tab();          // (once per evaluate!, not twice per row)
-    for (int r = c.lig; r < s.nn; r += GROUP) {
+    for (int r = c.lig; r < s.nn; r += c.lpi) {
         RowDesc rd;
         int tc[4];
         coop_rowdesc(c, s.row0 + r, rd, tc);
@@ -302,7 +319,7 @@ ACME_DEV bool coop_evaluate(const CoopCtx &c, const GenSub &s, int w_z, int o_lu
 // calc_Jp closure (src/ACME.jl:246-251) with the Jq of the latest evaluate!, written to w_dst where `pred`
 ACME_DEV void coop_calc_jp(const CoopCtx &c, const GenSub &s, int w_dst, bool pred) {
     const GenHeader &H = c.H;
-    for (int r = c.lig; r < s.nn; r += GROUP) {
+    for (int r = c.lig; r < s.nn; r += c.lpi) {
         RowDesc rd;
         int tc[4];
         coop_rowdesc(c, s.row0 + r, rd, tc);
@@ -335,26 +352,26 @@ ACME_DEV void coop_calc_jp(const CoopCtx &c, const GenSub &s, int w_dst, bool pr
 ACME_DEV bool coop_lu(const CoopCtx &c, int n, int o_f, int o_src) {
     double *W = c.W;
     const int ld = c.O.ld;
-    for (int i = c.lig; i < n; i += GROUP) W[o_src + i] = (double)i;
+    for (int i = c.lig; i < n; i += c.lpi) W[o_src + i] = (double)i;
     wv::wave_fence();
     bool ok = true;
     for (int k = 0; k < n; ++k) {
         double best = -1.0, bi = 1e9;
-        for (int i = c.lig; i < n; i += GROUP)
+        for (int i = c.lig; i < n; i += c.lpi)
             if (i >= k) {
                 const double v = fabs(W[o_f + i * ld + k]);
                 if (v > best) { best = v; bi = (double)i; }
             }
-        const double m = wv::allmax16(best);
+        const double m = coop_allmax(c, best);
         // the reference starts from (amax = 0, kp = k) and takes the first strictly larger entry: the smallest index
         // holding the maximum; an all-zero (or all-NaN) column keeps kp = k
-        double kpd = wv::allmin16((best == m && m > 0.0) ? bi : 1e9);
+        double kpd = coop_allmin(c, (best == m && m > 0.0) ? bi : 1e9);
         const int kp = kpd < (double)n ? (int)kpd : k;
         const double piv = W[o_f + kp * ld + k];
         ok = ok && piv != 0.0;
         wv::wave_fence();
         if (kp != k) {
-            for (int j = c.lig; j < n; j += GROUP) {
+            for (int j = c.lig; j < n; j += c.lpi) {
                 const double t = W[o_f + k * ld + j];
                 W[o_f + k * ld + j] = W[o_f + kp * ld + j];
                 W[o_f + kp * ld + j] = t;
@@ -372,7 +389,7 @@ ACME_DEV bool coop_lu(const CoopCtx &c, int n, int o_f, int o_src) {
         // (one row at a time: all of a lane's rows updated together -- pivot entries read once, every slot's operands
         // requested up front -- measured SLOWER, 135 000 against 96 000 cycles per sample: the predicated slots cost more
         // instructions than the shared reads save)
-        for (int i = c.lig; i < n; i += GROUP)
+        for (int i = c.lig; i < n; i += c.lpi)
             if (i > k) {
                 double *row = W + o_f + i * ld + k;
                 const double l = row[0] * inv;
@@ -411,7 +428,7 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
         constexpr int sl = decltype(sc)::value;
         xs[sl] = 0.0;
         if (sl < ns) {
-            const int i = c.lig + GROUP * sl;
+            const int i = c.lig + c.lpi * sl;
             xs[sl] = i < n ? W[w_x + (int)W[o_src + i]] : 0.0;
         }
     });
@@ -424,13 +441,13 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
                 double f[COOP_SLOTS];
                 sfor<sj, COOP_SLOTS>([&](auto sc) ACME_LAMBDA {          // (rows above slot sj are done)
                     constexpr int sl = decltype(sc)::value;
-                    const int i = c.lig + GROUP * sl;
+                    const int i = c.lig + c.lpi * sl;
                     f[sl] = (sl < ns && i > j && i < n) ? W[o_f + i * ld + j] : 0.0;
                 });
                 const double xj = wv::shfl16(xs[sj], jj);
                 sfor<sj, COOP_SLOTS>([&](auto sc) ACME_LAMBDA {
                     constexpr int sl = decltype(sc)::value;
-                    const int i = c.lig + GROUP * sl;
+                    const int i = c.lig + c.lpi * sl;
                     if (sl < ns && i > j && i < n) xs[sl] -= f[sl] * xj;
                 });
             }
@@ -445,13 +462,13 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
                 double f[COOP_SLOTS];
                 sfor<0, sj + 1>([&](auto sc) ACME_LAMBDA {
                     constexpr int sl = decltype(sc)::value;
-                    const int i = c.lig + GROUP * sl;
+                    const int i = c.lig + c.lpi * sl;
                     f[sl] = i < j ? W[o_f + i * ld + j] : 0.0;
                 });
                 const double xj = W[o_f + j * ld + j] * wv::shfl16(xs[sj], jj);
                 sfor<0, sj + 1>([&](auto sc) ACME_LAMBDA {
                     constexpr int sl = decltype(sc)::value;
-                    const int i = c.lig + GROUP * sl;
+                    const int i = c.lig + c.lpi * sl;
                     xs[sl] = i == j ? xj : (i < j ? xs[sl] - f[sl] * xj : xs[sl]);
                 });
             }
@@ -459,7 +476,7 @@ ACME_DEV void coop_lu_solve(const CoopCtx &c, int n, int o_f, int o_src, int w_x
     wv::wave_fence();
     sfor<0, COOP_SLOTS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int i = c.lig + GROUP * sl;
+        const int i = c.lig + c.lpi * sl;
         if (sl < ns && i < n) W[w_x + i] = xs[sl];
     });
     wv::wave_fence();
@@ -488,7 +505,7 @@ ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, dou
                                  double (&res)[COOP_REG_SLOTS], double (&tvr)[COOP_REG_SLOTS][4], const int (&rid)[COOP_REG_SLOTS]) {
     constexpr int NS = COOP_REG_SLOTS;
     const GenHeader &H = c.H;
-    for (int r = c.lig; r < s.nq; r += GROUP) {
+    for (int r = c.lig; r < s.nq; r += c.lpi) {
         c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
                                  : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
@@ -580,7 +597,7 @@ ACME_DEV bool coop_lu_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][
     int *Pk = reinterpret_cast<int *>(P + NC);
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {          // (a slot without a row: position -1, never a candidate, never updated)
         constexpr int sl = decltype(sc)::value;
-        pos[sl] = c.lig + GROUP * sl < n ? c.lig + GROUP * sl : -1;
+        pos[sl] = c.lig + c.lpi * sl < n ? c.lig + c.lpi * sl : -1;
     });
     bool ok = true;
     sfor<0, NC>([&](auto kc) ACME_LAMBDA {
@@ -724,7 +741,7 @@ ACME_DEV bool coop_gj_rows(const CoopCtx &c, int n, double (&a)[COOP_REG_SLOTS][
     sfor<0, 2>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
         rhs[sl] *= dinv[sl];
-        const bool real = c.lig + GROUP * sl < n;
+        const bool real = c.lig + c.lpi * sl < n;
         // a zero pivot (exactly singular in this order) or a NaN turns the row's result into NaN, an infinite pivot leaves
         // 1 / pivot = 0 behind (RowLU::solve_inplace)
         trip = trip || (real && (frz[sl] > COOP_PIVOT_THRESHOLD || !(rhs[sl] * 0.0 == 0.0) || dinv[sl] == 0.0));
@@ -739,7 +756,7 @@ ACME_DEV void coop_store_gj(const CoopCtx &c, int n, const double (&a)[COOP_REG_
     double *F = c.W + c.O.llu;
     sfor<0, COOP_REG_SLOTS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int p = c.lig + GROUP * sl;
+        const int p = c.lig + c.lpi * sl;
         if (pred && p < n) {
             sfor<0, NC / 2>([&](auto gc) ACME_LAMBDA {
                 constexpr int g = decltype(gc)::value;
@@ -760,7 +777,7 @@ template <int NC> ACME_DEV void coop_replay_gj(const CoopCtx &c, int n, int w_x)
     bool real[2];
     sfor<0, 2>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int p = c.lig + GROUP * sl;
+        const int p = c.lig + c.lpi * sl;
         real[sl] = p < n;
         x[sl] = real[sl] ? W[w_x + p] : 0.0;
         dinv[sl] = real[sl] ? F[p * c.O.ld + NC] : 0.0;
@@ -788,7 +805,7 @@ template <int NC> ACME_DEV void coop_replay_gj(const CoopCtx &c, int n, int w_x)
     wv::wave_fence();
     sfor<0, 2>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        if (real[sl]) W[w_x + c.lig + GROUP * sl] = x[sl] * dinv[sl];
+        if (real[sl]) W[w_x + c.lig + c.lpi * sl] = x[sl] * dinv[sl];
     });
     wv::wave_fence();
 }
@@ -838,38 +855,45 @@ ACME_DEV void coop_lu_lds_chunk(double *const (&row)[NS], const bool (&act)[NS],
     });
 }
 // One step of the factorisation (ODD: k is odd -- column k is the upper half of its pair).  vmx: the lane's largest |multiplier|.
-template <int NS, bool ODD>
+template <int NS, bool ODD, int LPI>
 ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
     double *F = c.W + c.O.llu;
     const int ld = c.O.ld, kc = k & ~1;                   // (kc: the pair holding column k)
-    const int ks = k / GROUP;                             // (the slots below ks hold rows above the pivot: not touched)
+    const int ks = k / LPI;                               // (the slots below ks hold rows above the pivot: not touched)
     const double *prow = F + k * ld;
     const wv::pair_t pp = wv::ld2(prow + kc);
     double *row[NS];
     wv::pair_t own[NS];
-    const bool real_last = c.lig + GROUP * (NS - 1) < n;
+    const bool real_last = c.lig + c.lpi * (NS - 1) < n;
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int p = c.lig + GROUP * sl;
+        const int p = c.lig + c.lpi * sl;
         row[sl] = F + ((sl < NS - 1 || real_last) ? p : n - 1) * ld;          // (a position beyond the matrix reads its last row, writes nothing)
         own[sl] = wv::pair_t{0.0, 0.0};
         if (sl >= ks) own[sl] = wv::ld2(row[sl] + kc);
     });
     // which of the pairs right of the pivot's hold anything in the pivot row -- of ANY of the wave's instances: lane l looks
-    // at pairs l, l + 16 (, l + 32 beyond 62 columns: the right-hand side's pair of a 64-unknown system)
+    // at pairs l, l + 16 (, l + 32 beyond 62 columns: the right-hand side's pair of a 64-unknown system); one instance per
+    // wave: lane l at pair l
     const int g0 = kc / 2 + 1, g1 = n / 2;                // first and last pair of the update (g1: the right-hand side's)
-    unsigned nzmask[3];
-    sfor<0, 3>([&](auto hc) ACME_LAMBDA {
-        constexpr int h = decltype(hc)::value;
-        nzmask[h] = 0u;
-        if (h < 2 || g1 >= 32) {
-            const int g = c.lig + GROUP * h;
-            const bool in = g >= g0 && g <= g1;
-            const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
-            const unsigned long long bal = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));          // (a NaN counts as something)
-            nzmask[h] = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
-        }
-    });
+    unsigned long long todo = 0ull;
+    if constexpr (LPI == 64) {
+        const int g = c.lig;
+        const bool in = g >= g0 && g <= g1;
+        const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
+        todo = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));          // (a NaN counts as something)
+    } else {
+        sfor<0, 3>([&](auto hc) ACME_LAMBDA {
+            constexpr int h = decltype(hc)::value;
+            if (h < 2 || g1 >= 32) {
+                const int g = c.lig + GROUP * h;
+                const bool in = g >= g0 && g <= g1;
+                const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
+                const unsigned long long bal = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));
+                todo |= ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << (GROUP * h);
+            }
+        });
+    }
     // read ahead: the four pairs next to the pivot's and the right-hand side's, of the pivot row and of the rows below
     constexpr int NB = 4;
     wv::pair_t bb[NB + 1], ab[NS][NB + 1];
@@ -891,7 +915,7 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
     bool act[NS];
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int p = c.lig + GROUP * sl;
+        const int p = c.lig + c.lpi * sl;
         const bool below = sl >= ks && p > k;
         const double a = ODD ? own[sl].hi : own[sl].lo;
         m[sl] = below ? -a * inv : 0.0;
@@ -903,8 +927,7 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
             else wv::st2(row[sl] + kc, below ? m[sl] : own[sl].lo, fma(m[sl], pp.hi, own[sl].hi));
         }
     });
-    if (c.lig == (k & (GROUP - 1))) c.W[c.O.dinv + k] = inv;
-    const unsigned long long todo = (unsigned long long)nzmask[0] | ((unsigned long long)nzmask[1] << 16) | ((unsigned long long)nzmask[2] << 32);
+    if (c.lig == k % LPI) c.W[c.O.dinv + k] = inv;
     COOP_T(c, CT_S_HEAD);
     // the pairs read ahead (the right-hand side's always -- on its own where it is not one of the four)
     sfor<0, NB + 1>([&](auto uc) ACME_LAMBDA {
@@ -943,9 +966,9 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
 // The triangular sweeps on x in registers (slot sl of the lane: position lig + 16 sl), the factors read from the lane's rows
 // in runs of eight columns, x_k broadcast by DPP.
 //   forward:  x_p += l_pk x_k  for p > k  (l: minus the multiplier, as stored), k ascending
-template <int NS> ACME_DEV void coop_lds_forward(int lig, int n, double (&x)[NS], const double *const (&row)[NS]) {
-    sfor<0, 2 * NS>([&](auto gc) ACME_LAMBDA {
-        constexpr int k0 = 8 * decltype(gc)::value, ks = k0 / GROUP;
+template <int NS, int LPI> ACME_DEV void coop_lds_forward(int lig, int n, double (&x)[NS], const double *const (&row)[NS]) {
+    sfor<0, NS * LPI / 8>([&](auto gc) ACME_LAMBDA {
+        constexpr int k0 = 8 * decltype(gc)::value, ks = k0 / LPI;
         if (k0 < n) {
             double m[NS][8];
             sfor<ks, NS>([&](auto sc) ACME_LAMBDA {
@@ -958,9 +981,11 @@ template <int NS> ACME_DEV void coop_lds_forward(int lig, int n, double (&x)[NS]
                 });
             });
             sfor<0, 8>([&](auto uc) ACME_LAMBDA {
-                constexpr int u = decltype(uc)::value, k = k0 + u, kl = k % GROUP;
+                constexpr int u = decltype(uc)::value, k = k0 + u, kl = k % LPI;
                 if (k0 + 8 <= n || k < n) {          // (whole runs are inside the model for all but the last)
-                    const double xk = wv::bcast16_ordered<kl, true>(x[ks]);
+                    double xk;
+                    if constexpr (LPI == 64) xk = wv::lane64<kl>(x[ks]);
+                    else xk = wv::bcast16_ordered<kl, true>(x[ks]);
                     x[ks] = lig > kl ? fma(m[ks][u], xk, x[ks]) : x[ks];
                     sfor<ks + 1, NS>([&](auto sc) ACME_LAMBDA { constexpr int sl = decltype(sc)::value; x[sl] = fma(m[sl][u], xk, x[sl]); });
                 }
@@ -970,9 +995,9 @@ template <int NS> ACME_DEV void coop_lds_forward(int lig, int n, double (&x)[NS]
 }
 //   backward: x_k <- x_k / u_kk,  x_p -= u_pk x_k  for p < k,  k descending (the division: times the stored 1 / pivot; the
 //   lanes' own x_p are scaled at the end, all at once -- x_p is not touched after its own step)
-template <int NS> ACME_DEV void coop_lds_backward(int lig, int n, double (&x)[NS], const double *const (&row)[NS], const double (&dinv)[NS]) {
-    sfor_down<2 * NS>([&](auto gc) ACME_LAMBDA {
-        constexpr int k0 = 8 * decltype(gc)::value, ks = k0 / GROUP;
+template <int NS, int LPI> ACME_DEV void coop_lds_backward(int lig, int n, double (&x)[NS], const double *const (&row)[NS], const double (&dinv)[NS]) {
+    sfor_down<NS * LPI / 8>([&](auto gc) ACME_LAMBDA {
+        constexpr int k0 = 8 * decltype(gc)::value, ks = k0 / LPI;
         if (k0 < n) {
             double m[NS][8];
             sfor<0, ks + 1>([&](auto sc) ACME_LAMBDA {
@@ -985,9 +1010,11 @@ template <int NS> ACME_DEV void coop_lds_backward(int lig, int n, double (&x)[NS
                 });
             });
             sfor_down<8>([&](auto uc) ACME_LAMBDA {
-                constexpr int u = decltype(uc)::value, k = k0 + u, kl = k % GROUP;
+                constexpr int u = decltype(uc)::value, k = k0 + u, kl = k % LPI;
                 if (k0 + 8 <= n || k < n) {
-                    const double xk = wv::bcast16_ordered<kl, true>(x[ks] * dinv[ks]);
+                    double xk;
+                    if constexpr (LPI == 64) xk = wv::lane64<kl>(x[ks] * dinv[ks]);
+                    else xk = wv::bcast16_ordered<kl, true>(x[ks] * dinv[ks]);
                     x[ks] = lig < kl ? fma(-m[ks][u], xk, x[ks]) : x[ks];
                     sfor<0, ks>([&](auto sc) ACME_LAMBDA { constexpr int sl = decltype(sc)::value; x[sl] = fma(-m[sl][u], xk, x[sl]); });
                 }
@@ -998,14 +1025,14 @@ template <int NS> ACME_DEV void coop_lds_backward(int lig, int n, double (&x)[NS
 }
 // [J | res] of the matrix at O.llu -> its factorisation, x = J^-1 res (unknown p at position p).  Returns (per lane)
 // whether its instance must not trust the result: threshold tripped, zero or non-finite pivot.
-template <int NS>
+template <int NS, int LPI>
 ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS]) {
     double vmx = 0.0;
     for (int k = 0; k < n; k += 2) {
-        coop_lu_lds_step<NS, false>(c, n, k, vmx);
+        coop_lu_lds_step<NS, false, LPI>(c, n, k, vmx);
         wv::lds_order();          // (a step reads what the step before wrote: the DS pipeline keeps a wave's program order)
         if (k + 1 < n) {
-            coop_lu_lds_step<NS, true>(c, n, k + 1, vmx);
+            coop_lu_lds_step<NS, true, LPI>(c, n, k + 1, vmx);
             wv::lds_order();
         }
     }
@@ -1019,13 +1046,13 @@ ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS]) {
     bool real[NS];
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int p = c.lig + GROUP * sl;
+        const int p = c.lig + c.lpi * sl;
         real[sl] = p < n;
         row[sl] = F + (real[sl] ? p : n - 1) * c.O.ld;
         dinv[sl] = c.W[c.O.dinv + (real[sl] ? p : 0)];
         x[sl] = real[sl] ? row[sl][n] : 0.0;          // (the right-hand side came through the forward sweep as a column)
     });
-    coop_lds_backward<NS>(c.lig, n, x, row, dinv);
+    coop_lds_backward<NS, LPI>(c.lig, n, x, row, dinv);
     bool trip = vmx > COOP_PIVOT_THRESHOLD;
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
@@ -1040,7 +1067,7 @@ template <int NS>
 ACME_DEV bool coop_evaluate_lds(const CoopCtx &c, const GenSub &s, int w_z, const int (&rid)[COOP_SLOTS], double (&res)[NS]) {
     const GenHeader &H = c.H;
     double *F = c.W + c.O.llu;
-    for (int r = c.lig; r < s.nq; r += GROUP) {
+    for (int r = c.lig; r < s.nq; r += c.lpi) {
         c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
                                  : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
@@ -1049,7 +1076,7 @@ ACME_DEV bool coop_evaluate_lds(const CoopCtx &c, const GenSub &s, int w_z, cons
     const wv::ExpTab etab = wv::load_exp_tab();
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int r = rid[sl], p = c.lig + GROUP * sl;
+        const int r = rid[sl], p = c.lig + c.lpi * sl;
         res[sl] = 0.0;
         if (r >= 0) {
             RowDesc rd;
@@ -1113,7 +1140,7 @@ template <int NS>
 ACME_DEV void coop_calc_jp_lds(const CoopCtx &c, const GenSub &s, bool pred, const int (&rid)[COOP_SLOTS]) {
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int r = rid[sl], p = c.lig + GROUP * sl;
+        const int r = rid[sl], p = c.lig + c.lpi * sl;
         if (r >= 0) {
             const int blk = (s.row0 + r) / GROUP, ln = (s.row0 + r) % GROUP;
             int tc[4];
@@ -1132,7 +1159,7 @@ ACME_DEV void coop_calc_jp_lds(const CoopCtx &c, const GenSub &s, bool pred, con
                     for (int u = 0; u < 4; ++u) {
                         double acc = 0.0;
                         for (int t = 0; t < 4; ++t) acc = fma(tv[t], cf[u][t], acc);
-                        if (pred && e + u < s.kp) c.W[c.O.ljp + col[u] * s.nn + r] = acc;
+                        if (pred && e + u < s.kp) c.W[c.O.ljp + (c.H.jp_sparse ? e + u : col[u]) * s.nn + r] = acc;
                     }
                 }
             } else
@@ -1155,7 +1182,7 @@ ACME_DEV void coop_calc_jp_lds(const CoopCtx &c, const GenSub &s, bool pred, con
 
 // x <- A^-1 x with the factorisation in the matrix (x at w_x: entry p the right-hand side of the row at position p on the
 // way in, unknown p on the way out)
-template <int NS> ACME_DEV void coop_replay_lds(const CoopCtx &c, int n, int w_x) {
+template <int NS, int LPI> ACME_DEV void coop_replay_lds(const CoopCtx &c, int n, int w_x) {
     double *W = c.W;
     const double *F = W + c.O.llu;
     double x[NS], dinv[NS];
@@ -1163,18 +1190,18 @@ template <int NS> ACME_DEV void coop_replay_lds(const CoopCtx &c, int n, int w_x
     bool real[NS];
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        const int p = c.lig + GROUP * sl;
+        const int p = c.lig + c.lpi * sl;
         real[sl] = p < n;
         row[sl] = F + (real[sl] ? p : n - 1) * c.O.ld;
         x[sl] = real[sl] ? W[w_x + p] : 0.0;
         dinv[sl] = W[c.O.dinv + (real[sl] ? p : 0)];
     });
-    coop_lds_forward<NS>(c.lig, n, x, row);
-    coop_lds_backward<NS>(c.lig, n, x, row, dinv);
+    coop_lds_forward<NS, LPI>(c.lig, n, x, row);
+    coop_lds_backward<NS, LPI>(c.lig, n, x, row, dinv);
     wv::wave_fence();
     sfor<0, NS>([&](auto sc) ACME_LAMBDA {
         constexpr int sl = decltype(sc)::value;
-        if (real[sl]) W[w_x + c.lig + GROUP * sl] = x[sl];
+        if (real[sl]) W[w_x + c.lig + c.lpi * sl] = x[sl];
     });
     wv::wave_fence();
 }
@@ -1182,7 +1209,7 @@ template <int NS> ACME_DEV void coop_replay_lds(const CoopCtx &c, int n, int w_x
 // the extrapolation's solve! of a kernel instantiated for NC columns (0: the LDS version, any size)
 template <int NC> ACME_DEV void coop_backsolve(const CoopCtx &c, int n, int o_f, int o_src, int w_x) {
     if constexpr (NC > 0) coop_replay_gj<NC>(c, n, w_x);
-    else if constexpr (NC < 0) coop_replay_lds<-NC>(c, n, w_x);
+    else if constexpr (NC < 0) coop_replay_lds<coop_ns(NC), coop_lpi(NC)>(c, n, w_x);
     else coop_lu_solve(c, n, o_f, o_src, w_x);
 }
 
@@ -1239,7 +1266,7 @@ ACME_DEV void coop_linearize(const CoopCtx &c, const GenSub &s, CoopSolver &f, i
             wv::wave_fence();
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                const int p = c.lig + GROUP * sl;
+                const int p = c.lig + c.lpi * sl;
                 if (learn && p < nn) {
                     f.rid[sl] = ob[p];
                     f.last[sl] = p;          // (where this row would end if the same matrix were factored again)
@@ -1276,7 +1303,7 @@ ACME_DEV void coop_linearize(const CoopCtx &c, const GenSub &s, CoopSolver &f, i
 // coop_linearize on the matrix in LDS: evaluate!(nleq, z at w_z) into the instance's one matrix, the elimination in place;
 // x = J^-1 res (unknown p at position p).  Learning a new order: the reference's pivoting on the same matrix (coop_lu: real
 // interchanges, the gather src[] says which of the present positions' rows ends where), adopted, and everything once more.
-template <int NS>
+template <int NS, int LPI>
 ACME_DEV void coop_linearize_lds(const CoopCtx &c, const GenSub &s, CoopSolver &f, int w_z, bool act, double (&x)[NS], double &resmax, bool &ok) {
     const int nn = s.nn;
     int phase = 0;
@@ -1292,12 +1319,12 @@ ACME_DEV void coop_linearize_lds(const CoopCtx &c, const GenSub &s, CoopSolver &
             int *ob = reinterpret_cast<int *>(c.W + c.O.xb);
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                if (f.rid4[sl] >= 0) ob[c.lig + GROUP * sl] = f.rid4[sl];
+                if (f.rid4[sl] >= 0) ob[c.lig + c.lpi * sl] = f.rid4[sl];
             });
             wv::wave_fence();
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                const int p = c.lig + GROUP * sl;
+                const int p = c.lig + c.lpi * sl;
                 if (learn && p < nn) f.rid4[sl] = ob[(int)c.W[c.O.lsrc + p]];
             });
             wv::wave_fence();
@@ -1312,9 +1339,9 @@ ACME_DEV void coop_linearize_lds(const CoopCtx &c, const GenSub &s, CoopSolver &
             const double v = fabs(res[sl]);
             if (f.rid4[sl] >= 0 && v > rm) rm = v;
         });
-        resmax = wv::allmax16(rm);
+        resmax = coop_allmax(c, rm);
         if (!finite) resmax = (double)NAN;
-        const bool trip = coop_lu_lds<NS>(c, nn, x);
+        const bool trip = coop_lu_lds<NS, LPI>(c, nn, x);
         COOP_T(c, CT_LU);
         if (phase == 0) {
             learn = act && finite && trip;
@@ -1355,7 +1382,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
         COOP_T(c, CT_SETP);
         if constexpr (NC < 0) {
             // (Jp by residual row: position p takes the row it holds; from the row's sparse form where the image has it)
-            for (int sl = 0; sl < -NC; ++sl) {
+            for (int sl = 0; sl < coop_ns(NC); ++sl) {
                 const int r = f.rid4[sl];
                 if (r < 0) continue;
                 double acc = 0.0;
@@ -1365,7 +1392,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
                         for (int u = 0; u < 4; ++u) {
                             const int ee = e + u < s.kp ? e + u : s.kp - 1;
                             const int col = (int)c.M[s.o_pcol + ee * nn + r];
-                            jv[u] = W[c.O.ljp + col * nn + r];
+                            jv[u] = W[c.O.ljp + (H.jp_sparse ? ee : col) * nn + r];
                             dv[u] = W[w_p + col] - W[c.O.lp + col];
                         }
                         for (int u = 0; u < 4; ++u)
@@ -1374,14 +1401,14 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
                 } else {
                     acc = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
                 }
-                W[c.O.tmp + c.lig + GROUP * sl] = acc;
+                W[c.O.tmp + c.lig + c.lpi * sl] = acc;
             }
         } else {
-            for (int r = c.lig; r < nn; r += GROUP) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
+            for (int r = c.lig; r < nn; r += c.lpi) W[c.O.tmp + r] = coop_dot_diff(W + c.O.ljp + r, nn, W + w_p, W + c.O.lp, np, 0.0);
         }
         wv::wave_fence();
         coop_backsolve<NC>(c, nn, f.o_llu, f.o_lsrc, c.O.tmp);
-        for (int r = c.lig; r < nn; r += GROUP)
+        for (int r = c.lig; r < nn; r += c.lpi)
             if (need) W[c.O.zz + r] = W[c.O.lz + r] - W[c.O.tmp + r];
         wv::wave_fence();
         COOP_T(c, CT_EXTRAP);
@@ -1390,7 +1417,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
     double reslast = 0.0;
     its = 0;
     if constexpr (NC != 0) {
-        constexpr int NS = NC > 0 ? COOP_REG_SLOTS : -NC;
+        constexpr int NS = NC > 0 ? COOP_REG_SLOTS : coop_ns(NC);
         int stage = wv::ballot(reorig) != 0ull ? 0 : 1;          // 0: re-linearising at the origin; 1: the start is due; 2: Newton
         for (;;) {
             if (stage == 0) {
@@ -1408,7 +1435,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             double a[COOP_REG_SLOTS][NCR], res[NS], tv[COOP_REG_SLOTS][4], dinv[COOP_REG_SLOTS], resmax;
             bool ok;
             if constexpr (NC > 0) coop_linearize<NC>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, a, res, tv, dinv, resmax, ok);
-            else coop_linearize_lds<NS>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, res, resmax, ok);
+            else coop_linearize_lds<NS, coop_lpi(NC)>(c, s, f, origin ? c.O.lz : c.O.zz, origin ? reorig : act, res, resmax, ok);
             const bool finite = resmax == resmax;
             const bool small = resmax < c.A.tol;
             const bool accept = !origin && act && finite && ok && small;
@@ -1417,7 +1444,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             // the Newton step came out of the elimination: unknown p at position p
             sfor<0, NS>([&](auto sc) ACME_LAMBDA {
                 constexpr int sl = decltype(sc)::value;
-                const int p = c.lig + GROUP * sl;
+                const int p = c.lig + c.lpi * sl;
                 if (step && p < nn) W[c.O.zz + p] -= res[sl];
             });
             COOP_T(c, CT_SOLVE);
@@ -1432,9 +1459,9 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
                 } else {
                     coop_calc_jp_lds<NS>(c, s, rec, f.rid4);          // (the matrix is the record already)
                 }
-                for (int j = c.lig; j < np; j += GROUP)
+                for (int j = c.lig; j < np; j += c.lpi)
                     if (accept) W[c.O.lp + j] = W[w_p + j];
-                for (int r = c.lig; r < nn; r += GROUP)
+                for (int r = c.lig; r < nn; r += c.lpi)
                     if (accept) W[c.O.lz + r] = W[c.O.zz + r];
             }
             wv::wave_fence();
@@ -1456,7 +1483,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             COOP_T(c, CT_EVAL);
             const bool finite = !coop_any(c, bad);
             double rm = 0.0;
-            for (int r = c.lig; r < nn; r += GROUP) {
+            for (int r = c.lig; r < nn; r += c.lpi) {
                 const double v = fabs(W[c.O.res + r]);
                 if (v > rm) rm = v;
             }
@@ -1469,19 +1496,19 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
             const bool step = act && finite && ok && !small;
             reslast = act ? resmax : reslast;
             // the Newton step (for everyone; only the stepping instances keep it)
-            for (int r = c.lig; r < nn; r += GROUP) W[c.O.dz + r] = W[c.O.res + r];
+            for (int r = c.lig; r < nn; r += c.lpi) W[c.O.dz + r] = W[c.O.res + r];
             wv::wave_fence();
             coop_backsolve<NC>(c, nn, f.o_lu, f.o_src, c.O.dz);
-            for (int r = c.lig; r < nn; r += GROUP)
+            for (int r = c.lig; r < nn; r += c.lpi)
                 if (step) W[c.O.zz + r] -= W[c.O.dz + r];
             COOP_T(c, CT_SOLVE);
             // an accepted iterate: its factors, Jp, p and z become the extrapolation origin
             if (wv::ballot(accept) != 0ull) {
                 coop_calc_jp(c, s, c.O.ljp, accept);
                 coop_accept_factors(f, accept);
-                for (int j = c.lig; j < np; j += GROUP)
+                for (int j = c.lig; j < np; j += c.lpi)
                     if (accept) W[c.O.lp + j] = W[w_p + j];
-                for (int r = c.lig; r < nn; r += GROUP)
+                for (int r = c.lig; r < nn; r += c.lpi)
                     if (accept) W[c.O.lz + r] = W[c.O.zz + r];
             }
             wv::wave_fence();
@@ -1514,19 +1541,19 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
             const double pj = W[w_p + j];
             const double dl = pj - W[c.O.lp + j];
             best = fma(dl, dl, best);
-            const double t = (c.valid ? cp[j * CACHE + c.lig] : 0.0) - pj;
+            const double t = (c.valid ? cp[j * CACHE + (c.lig & (CACHE - 1))] : 0.0) - pj;
             d = fma(t, t, d);
         }
         d = c.lig < count ? d : (double)INFINITY;
-        const double m = wv::allmin16(d);
+        const double m = coop_allmin(c, d);
         const unsigned long long bal = wv::ballot(d == m);
         const int idx = wv::ffs32((int)((bal >> (c.grp * GROUP)) & 0xFFFFull)) - 1;
         const bool hit = need && count > 0 && m < best;
         if (wv::ballot(hit) != 0ull) {
             const int e = hit ? idx : 0;
-            for (int j = c.lig; j < np; j += GROUP)
+            for (int j = c.lig; j < np; j += c.lpi)
                 if (hit) W[c.O.lp + j] = cp[j * CACHE + e];
-            for (int r = c.lig; r < nn; r += GROUP)
+            for (int r = c.lig; r < nn; r += c.lpi)
                 if (hit) W[c.O.lz + r] = cz[e * nn + r];
             wv::wave_fence();
             if constexpr (NC != 0) reorig = reorig || hit;         // (a pass of coop_simple_solve's loop)
@@ -1541,9 +1568,9 @@ template <int NC> ACME_DEV bool coop_cached_solve(const CoopCtx &c, const GenSub
             const int count = c.valid ? meta[0] : 0, head = c.valid ? meta[1] : 0;
             const int slot = count < CACHE ? count : head;
             wv::wave_fence();
-            for (int j = c.lig; j < np; j += GROUP)
+            for (int j = c.lig; j < np; j += c.lpi)
                 if (keep) cp[j * CACHE + slot] = W[w_p + j];
-            for (int r = c.lig; r < nn; r += GROUP)
+            for (int r = c.lig; r < nn; r += c.lpi)
                 if (keep && c.wr) cz[slot * nn + r] = W[c.O.zz + r];
             if (keep && c.lig == 0) {
                 meta[0] = count < CACHE ? count + 1 : count;
@@ -1575,7 +1602,7 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
             need = need && !cv && c.A.solver != SOLVER_SIMPLE;
             direct = false;
             if (wv::ballot(need) != 0ull) {
-                for (int j = c.lig; j < s.np; j += GROUP)
+                for (int j = c.lig; j < s.np; j += c.lpi)
                     if (need) W[c.O.sp + j] = W[c.O.lp + j];
                 wv::wave_fence();
             }
@@ -1593,7 +1620,7 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
             need = need && best < 1.0;
         }
         if (wv::ballot(need) == 0ull) break;
-        for (int j = c.lig; j < s.np; j += GROUP) {
+        for (int j = c.lig; j < s.np; j += c.lpi) {
             double pa = W[c.O.sp + j] * (1.0 - a);
             pa = pa + a * W[c.O.p + j];
             if (need) W[c.O.pa + j] = pa;
@@ -1611,7 +1638,8 @@ template <int NC> ACME_DEV bool coop_homotopy_solve(const CoopCtx &c, const GenS
 // barrier behind the staging a wave never talks to another.
 template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds, int wave_in_block, int wave_global, int lane) {
     const GenHeader &H = *A.H;
-    const int lig = lane & (GROUP - 1), grp = lane >> 4;
+    constexpr int LPI = coop_lpi(NC);          // lanes per instance
+    const int lig = lane & (LPI - 1), grp = lane / LPI;
     const int gpw = A.coop_gpw, wpb = A.coop_wpb;
     lds = static_cast<double *>(__builtin_assume_aligned(lds, 16));
     // ---- the block's shared part: model image (if shared) and row tables, loaded by all its lanes ----
@@ -1649,7 +1677,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     const CoopOff O = coop_offsets(H, NC);
     double *W = lds + coop_shared_doubles(H, IMGL, NC) + (long long)(wave_in_block * gpw + (wr ? grp : 0)) * coop_inst_doubles(H, NC);
     double *Cp = W + ((O.total + 1) & ~1);
-    CoopCtx c{A, H, O, IMGL ? img - img0 : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, i, valid, wr};
+    CoopCtx c{A, H, O, IMGL ? img - img0 : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, LPI, i, valid, wr};
 #ifdef ACME_COOP_TIMING
     CoopTimer tmr{};
     tmr.mark = (long long)__builtin_readcyclecounter();
@@ -1664,24 +1692,24 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     // at the slots' positions
     if constexpr (NC > 0)
         for (int sl = 0; sl < 2; ++sl) {
-            const int p = lig + GROUP * sl;
+            const int p = lig + LPI * sl;
             f.rid[sl] = (has_sub && p < s.nn) ? A.coop_order[i * COOP_MAX_N + p] : -1;
         }
     if constexpr (NC < 0)
-        for (int sl = 0; sl < -NC; ++sl) {
-            const int p = lig + GROUP * sl;
+        for (int sl = 0; sl < coop_ns(NC); ++sl) {
+            const int p = lig + LPI * sl;
             f.rid4[sl] = (has_sub && p < s.nn) ? A.coop_order[i * COOP_MAX_N + p] : -1;
         }
     const bool caching = has_sub && A.solver == SOLVER_CACHING_HOMOTOPY;
     double *cache_g = A.cache + i * H.cache_total + (has_sub ? s.c_off : 0);
-    for (int k = lig; k < O.total; k += GROUP) W[k] = 0.0;
+    for (int k = lig; k < O.total; k += LPI) W[k] = 0.0;
     wv::wave_fence();
-    for (int k = lig; k < H.nx; k += GROUP) W[c.O.x + k] = st[k];
+    for (int k = lig; k < H.nx; k += LPI) W[c.O.x + k] = st[k];
     if (has_sub) {
-        for (int j = lig; j < s.np; j += GROUP) W[c.O.lp + j] = st[H.nx + s.poff + j];
-        for (int r = lig; r < s.nn; r += GROUP) W[c.O.lz + r] = st[H.nx + H.npt + s.zoff + r];
+        for (int j = lig; j < s.np; j += LPI) W[c.O.lp + j] = st[H.nx + s.poff + j];
+        for (int r = lig; r < s.nn; r += LPI) W[c.O.lz + r] = st[H.nx + H.npt + s.zoff + r];
         if (caching)       // the stored p's and the two counters live in LDS for the launch
-            for (int k = lig; k < s.np * CACHE + 2; k += GROUP) Cp[k] = cache_g[k];
+            for (int k = lig; k < s.np * CACHE + 2; k += LPI) Cp[k] = cache_g[k];
     }
     wv::wave_fence();
     if constexpr (NC == 0)
@@ -1691,19 +1719,19 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     // this sample's inputs sit in LDS (GenHeader::w_u); the next sample's are requested a sample ahead (HBM latency)
     double upre[COOP_SLOTS];
     for (int sl = 0; sl < COOP_SLOTS; ++sl) {
-        const int k = lig + GROUP * sl;
+        const int k = lig + LPI * sl;
         upre[sl] = (k < H.nu && A.T > 0) ? A.u[(i * A.T) * H.nu + k] : 0.0;
     }
     for (long long n = 0; n < A.T; ++n) {
         double *yn = A.y + (i * A.T + n) * H.ny;
         // inputs of this sample into LDS, the next sample's requested
         for (int sl = 0; sl < COOP_SLOTS; ++sl) {
-            const int k = lig + GROUP * sl;
+            const int k = lig + LPI * sl;
             if (k < H.nu) W[c.O.u + k] = upre[sl];
         }
         wv::wave_fence();
         for (int sl = 0; sl < COOP_SLOTS; ++sl) {
-            const int k = lig + GROUP * sl;
+            const int k = lig + LPI * sl;
             if (k < H.nu && n + 1 < A.T) upre[sl] = A.u[(i * A.T + n + 1) * H.nu + k];
         }
         const double *un = W + c.O.u;
@@ -1712,7 +1740,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         long long its_sample = 0;
         if (has_sub) {
             // p = dq x + eq u  (src/ACME.jl:678-683; a first sub-problem has no fqprev term)
-            for (int r = lig; r < s.np; r += GROUP) {
+            for (int r = lig; r < s.np; r += LPI) {
                 double acc;
                 if (H.ell) {
                     acc = coop_ell_dot(c.M, s.e_dq, r, W + c.O.x, 0.0);
@@ -1731,7 +1759,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             const bool failed = alive && !conv;
             if (wv::ballot(failed) != 0ull) {            // the policy of step! (src/ACME.jl:688-694)
                 bool nf = false;
-                for (int r = lig; r < s.nn; r += GROUP) nf = nf || !(W[c.O.zz + r] * 0.0 == 0.0);
+                for (int r = lig; r < s.nn; r += LPI) nf = nf || !(W[c.O.zz + r] * 0.0 == 0.0);
                 const bool zfinite = !coop_any(c, nf);
                 if (failed && lig == 0 && wr) {
                     if (zfinite) {
@@ -1743,7 +1771,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
                 }
                 dead = dead || (failed && !zfinite);
             }
-            for (int r = lig; r < s.nn; r += GROUP)
+            for (int r = lig; r < s.nn; r += LPI)
                 if (alive) W[c.O.z + s.zoff + r] = W[c.O.zz + r];
             wv::wave_fence();
         }
@@ -1754,7 +1782,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         // y = y0 + dy x + ey u + fy z (old x, :699-706);  x = x0 + a x + b u + c z (:708-714)
         // (ONE pass over the nx + ny rows -- a lane takes a state row or an output row, the vectors are the same: the two
         // loops cost two sets of latencies for mostly idle lanes)
-        for (int rho = lig; rho < H.nx + H.ny; rho += GROUP) {
+        for (int rho = lig; rho < H.nx + H.ny; rho += LPI) {
             const bool isx = rho < H.nx;
             const int r = isx ? rho : rho - H.nx, ldm = isx ? H.nx : H.ny;
             double acc;
@@ -1774,7 +1802,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             }
         }
         wv::wave_fence();
-        for (int r = lig; r < H.nx; r += GROUP)
+        for (int r = lig; r < H.nx; r += LPI)
             if (live) W[c.O.x + r] = W[c.O.xn + r];
         wv::wave_fence();
         COOP_T(c, CT_XY);
@@ -1784,18 +1812,18 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
         for (int k = 0; k < CT_N; ++k) A.y[(i * A.T + k) * H.ny] = (double)tmr.t[k];
 #endif
     if (wr)
-        for (int k = lig; k < H.nx; k += GROUP) st[k] = W[c.O.x + k];
+        for (int k = lig; k < H.nx; k += LPI) st[k] = W[c.O.x + k];
     if (has_sub && wr) {
-        for (int j = lig; j < s.np; j += GROUP) st[H.nx + s.poff + j] = W[c.O.lp + j];
-        for (int r = lig; r < s.nn; r += GROUP) st[H.nx + H.npt + s.zoff + r] = W[c.O.lz + r];
+        for (int j = lig; j < s.np; j += LPI) st[H.nx + s.poff + j] = W[c.O.lp + j];
+        for (int r = lig; r < s.nn; r += LPI) st[H.nx + H.npt + s.zoff + r] = W[c.O.lz + r];
         if (caching)
-            for (int k = lig; k < s.np * CACHE + 2; k += GROUP) cache_g[k] = Cp[k];
+            for (int k = lig; k < s.np * CACHE + 2; k += LPI) cache_g[k] = Cp[k];
         if constexpr (NC > 0)          // (a run split over several launches repeats the one-launch arithmetic)
             for (int sl = 0; sl < 2; ++sl)
-                if (lig + GROUP * sl < s.nn) A.coop_order[i * COOP_MAX_N + lig + GROUP * sl] = f.rid[sl];
+                if (lig + LPI * sl < s.nn) A.coop_order[i * COOP_MAX_N + lig + LPI * sl] = f.rid[sl];
         if constexpr (NC < 0)
-            for (int sl = 0; sl < -NC; ++sl)
-                if (lig + GROUP * sl < s.nn) A.coop_order[i * COOP_MAX_N + lig + GROUP * sl] = f.rid4[sl];
+            for (int sl = 0; sl < coop_ns(NC); ++sl)
+                if (lig + LPI * sl < s.nn) A.coop_order[i * COOP_MAX_N + lig + LPI * sl] = f.rid4[sl];
     }
     if (lig == 0 && wr) {
         rep[RW_ITERS_TOTAL] += it_total;

@@ -30,6 +30,7 @@ const void *acme_coop_fn_lds1(int imgl);          // (the threshold path on a ma
 const void *acme_coop_fn_lds2(int imgl);
 const void *acme_coop_fn_lds3(int imgl);
 const void *acme_coop_fn_lds4(int imgl);
+const void *acme_coop_fn_wave64(int imgl);        // (... and with one instance per wave, one row per lane: NC = COOP_WAVE64)
 template <int NC> static inline const void *coop_fns_of(int imgl) {
     return imgl ? (const void *)acme_coop_kernel<true, NC> : (const void *)acme_coop_kernel<false, NC>;
 }

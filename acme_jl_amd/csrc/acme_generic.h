@@ -52,6 +52,8 @@ struct GenHeader {
     int ell;                 // the sparse forms below and in sub[0] exist and hold every non-zero of this model (a batch: of every
                              // instance's model) -- the mid-size kernel reads them instead of the dense matrices
     int o_ell;               // where the sparse part of the image begins (an even offset; image_total if there is none)
+    int jp_sparse;           // the mid-size kernel on a matrix in LDS keeps Jp as the kp entries per row of its sparse form, not as
+                             // np columns (set by the host for a batch that shares ONE model image: its sparse forms cannot change)
     GenEll e_ax, e_bu, e_cz; // [a; dy], [b; ey], [c; fy]: the nx state rows followed by the ny output rows
     int o_xy0;               // x0 followed by y0
     int nnmax, nqmax, npmax;

@@ -173,6 +173,7 @@ static inline const void *coop_fn(const GArgs &A) {
     case -2: return acme_coop_fn_lds2(A.coop_imgl);
     case -3: return acme_coop_fn_lds3(A.coop_imgl);
     case -4: return acme_coop_fn_lds4(A.coop_imgl);
+    case COOP_WAVE64: return acme_coop_fn_wave64(A.coop_imgl);
     default: return coop_fns_of<0>(A.coop_imgl);
     }
 }

@@ -418,12 +418,28 @@ ACME_DEV double allmax16_nn(double v) {
 }
 
 // min / sum over the 16 lanes of each row, result in every lane
+// the value lane K of the WAVE holds, in every lane (v_readlane_b32: through the scalar registers -- the mid-size kernel's
+// one-instance-per-wave instantiation broadcasts x_k of its triangular sweeps this way)
+template <int K> ACME_DEV double lane64(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), K);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), K);
+    return __hiloint2double(hi, lo);
+}
 ACME_DEV double allmin16(double v) {
     v = fmin(v, ror16<8>(v));
     v = fmin(v, ror16<4>(v));
     v = fmin(v, ror16<2>(v));
     v = fmin(v, ror16<1>(v));
     return v;
+}
+// maximum / minimum over the whole wave, in every lane
+ACME_DEV double allmax64(double v) {
+    v = allmax16(v);
+    return fmax(fmax(lane64<0>(v), lane64<16>(v)), fmax(lane64<32>(v), lane64<48>(v)));
+}
+ACME_DEV double allmin64(double v) {
+    v = allmin16(v);
+    return fmin(fmin(lane64<0>(v), lane64<16>(v)), fmin(lane64<32>(v), lane64<48>(v)));
 }
 ACME_DEV double allsum16(double v) {
     v += ror16<8>(v);

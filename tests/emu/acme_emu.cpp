@@ -274,6 +274,7 @@ static void coop_fiber_entry(void *p) {
     case -2: img ? coop_main<true, -2>(*c->A, lds, wave, wg, lane) : coop_main<false, -2>(*c->A, lds, wave, wg, lane); break;
     case -3: img ? coop_main<true, -3>(*c->A, lds, wave, wg, lane) : coop_main<false, -3>(*c->A, lds, wave, wg, lane); break;
     case -4: img ? coop_main<true, -4>(*c->A, lds, wave, wg, lane) : coop_main<false, -4>(*c->A, lds, wave, wg, lane); break;
+    case COOP_WAVE64: img ? coop_main<true, COOP_WAVE64>(*c->A, lds, wave, wg, lane) : coop_main<false, COOP_WAVE64>(*c->A, lds, wave, wg, lane); break;
     default: img ? coop_main<true, 0>(*c->A, lds, wave, wg, lane) : coop_main<false, 0>(*c->A, lds, wave, wg, lane); break;
     }
 }

@@ -257,6 +257,15 @@ ACME_DEV double allmin16(double v) {
     v = fmin(v, ror16<1>(v));
     return v;
 }
+template <int K> ACME_DEV double lane64(double v) { return emu::u2d(emu::exchange(emu::d2u(v), K, 600 + K)); }
+ACME_DEV double allmax64(double v) {
+    v = allmax16(v);
+    return fmax(fmax(lane64<0>(v), lane64<16>(v)), fmax(lane64<32>(v), lane64<48>(v)));
+}
+ACME_DEV double allmin64(double v) {
+    v = allmin16(v);
+    return fmin(fmin(lane64<0>(v), lane64<16>(v)), fmin(lane64<32>(v), lane64<48>(v)));
+}
 ACME_DEV double allsum16(double v) {
     v += ror16<8>(v);
     v += ror16<4>(v);

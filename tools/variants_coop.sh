@@ -7,7 +7,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/acme_jl_amd/csrc; out=/tmp/variants_coop_$name
 mkdir -p $out $root/build_variants
-for u in acme_hip acme_hip_coop20 acme_hip_coop24 acme_hip_coop28 acme_hip_coop32 acme_hip_coopl1 acme_hip_coopl2 acme_hip_coopl3 acme_hip_coopl4; do
+for u in acme_hip acme_hip_coop20 acme_hip_coop24 acme_hip_coop28 acme_hip_coop32 acme_hip_coopl1 acme_hip_coopl2 acme_hip_coopl3 acme_hip_coopl4 acme_hip_coopw; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -join-splitedges=1 "$@" -c $src/$u.hip -o $out/$u.o 2> $out/$u.log &
 done
 wait
