@@ -148,6 +148,7 @@ struct CoopCtx {
     const int *ti;           // ... and the rows' ints ([blk][ROWI][16])
     int lig, grp;
     int lpi;                 // lanes per instance: 16 (one instance per DPP row) or 64 (COOP_WAVE64: one instance per wave)
+    bool ell;                // this instantiation reads the sparse forms of the model's matrices (coop_reads_sparse)
     long long i;
     bool valid;
     bool wr;                 // this row of 16 lanes writes to global memory (false: it mirrors the wave's first row, coop_main)
@@ -164,8 +165,13 @@ ACME_HD inline int coop_cache_doubles(const GenHeader &H) { return H.nsub > 0 ? 
 ACME_HD inline int coop_inst_doubles(const GenHeader &H, int nc) { return ((coop_offsets(H, nc).total + 1) & ~1) + coop_cache_doubles(H); }
 // what a block stages of a shared model image: all of it -- or, for the instantiations on a matrix in LDS when the image has
 // its sparse forms (GenHeader::ell), only those: they read nothing else
-ACME_HD inline int coop_image_first(const GenHeader &H, int nc) { return nc < 0 && H.ell ? H.o_ell : 0; }
-ACME_HD inline int coop_image_doubles(const GenHeader &H, int nc) { return (H.image_total - coop_image_first(H, nc) + 1) & ~1; }
+// (the register instantiations and the literal one read the dense matrices -- from an image in LDS one round trip per
+// batch of operands, where the sparse forms take two: the column numbers first -- and stage only those)
+ACME_HD inline bool coop_reads_sparse(const GenHeader &H, int nc) { return nc < 0 && H.ell != 0; }
+ACME_HD inline int coop_image_first(const GenHeader &H, int nc) { return coop_reads_sparse(H, nc) ? H.o_ell : 0; }
+ACME_HD inline int coop_image_doubles(const GenHeader &H, int nc) {
+    return ((coop_reads_sparse(H, nc) ? H.image_total : H.o_ell) - coop_image_first(H, nc) + 1) & ~1;
+}
 ACME_HD inline int coop_shared_doubles(const GenHeader &H, bool shared_image, int nc) {
     return (shared_image ? coop_image_doubles(H, nc) : 0) + coop_table_doubles(H);
 }
@@ -266,7 +272,7 @@ ACME_DEV void coop_rowdesc(const CoopCtx &c, int R, RowDesc &rd, int (&tc)[4]) {
 // pfull <- q0 + pexp p  (set_p closure, src/ACME.jl:237-243); p at w_p must be visible (fenced)
 ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
     for (int r = c.lig; r < s.nq; r += c.lpi) {
-        c.W[c.O.pf + r] = c.H.ell ? coop_ell_dot(c.M, s.e_pexp, r, c.W + w_p, c.M[s.o_q0s + r])
+        c.W[c.O.pf + r] = c.ell ? coop_ell_dot(c.M, s.e_pexp, r, c.W + w_p, c.M[s.o_q0s + r])
                                   : coop_dot(c.M + s.o_pexp + r, s.nq, c.W + w_p, s.np, c.M[s.o_q0 + r]);
     }
     wv::wave_fence();
@@ -278,7 +284,7 @@ ACME_DEV void coop_set_p(const CoopCtx &c, const GenSub &s, int w_p) {
 ACME_DEV bool coop_evaluate(const CoopCtx &c, const GenSub &s, int w_z, int o_lu) {
     const GenHeader &H = c.H;
     for (int r = c.lig; r < s.nq; r += c.lpi) {
-        c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
+        c.W[c.O.q + r] = c.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
                                  : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
@@ -506,7 +512,7 @@ ACME_DEV bool coop_evaluate_rows(const CoopCtx &c, const GenSub &s, int w_z, dou
     constexpr int NS = COOP_REG_SLOTS;
     const GenHeader &H = c.H;
     for (int r = c.lig; r < s.nq; r += c.lpi) {
-        c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
+        c.W[c.O.q + r] = c.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
                                  : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
@@ -1068,7 +1074,7 @@ ACME_DEV bool coop_evaluate_lds(const CoopCtx &c, const GenSub &s, int w_z, cons
     const GenHeader &H = c.H;
     double *F = c.W + c.O.llu;
     for (int r = c.lig; r < s.nq; r += c.lpi) {
-        c.W[c.O.q + r] = c.H.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
+        c.W[c.O.q + r] = c.ell ? coop_ell_dot(c.M, s.e_fq, r, c.W + w_z, c.W[c.O.pf + r])
                                  : coop_dot(c.M + s.o_fq + r, s.nq, c.W + w_z, s.nn, c.W[c.O.pf + r]);
     }
     wv::wave_fence();
@@ -1093,7 +1099,7 @@ ACME_DEV bool coop_evaluate_lds(const CoopCtx &c, const GenSub &s, int w_z, cons
             wv::st2(c.W + c.O.tv + 4 * p, tv[0], tv[1]);
             wv::st2(c.W + c.O.tv + 4 * p + 2, tv[2], tv[3]);
             double *row = F + p * c.O.ld;
-            if (H.ell) {
+            if (c.ell) {
                 // J row = Jq row * fq from the row's sparse form (GenSub::o_jcol): zeros, then the columns that hold anything
                 for (int j = 0; j < c.O.ld; j += 2) wv::st2(row + j, 0.0, 0.0);
                 for (int e = 0; e < s.kj; e += 4) {
@@ -1147,7 +1153,7 @@ ACME_DEV void coop_calc_jp_lds(const CoopCtx &c, const GenSub &s, bool pred, con
             double tv[4];
             for (int t = 0; t < 4; ++t) tc[t] = c.ti[blk * ROWI * GROUP + (3 + t) * GROUP + ln];
             for (int t = 0; t < 4; ++t) tv[t] = c.W[c.O.tv + 4 * p + t];
-            if (c.H.ell) {
+            if (c.ell) {
                 for (int e = 0; e < s.kp; e += 4) {
                     int col[4];
                     double cf[4][4];
@@ -1386,7 +1392,7 @@ template <int NC> ACME_DEV bool coop_simple_solve(const CoopCtx &c, const GenSub
                 const int r = f.rid4[sl];
                 if (r < 0) continue;
                 double acc = 0.0;
-                if (H.ell) {
+                if (c.ell) {
                     for (int e = 0; e < s.kp; e += 4) {
                         double jv[4], dv[4];
                         for (int u = 0; u < 4; ++u) {
@@ -1650,7 +1656,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     int *ti = reinterpret_cast<int *>(tk + blocks * 8 * GROUP);
     const int t0 = wave_in_block * 64 + lane, tstep = wpb * 64;
     if constexpr (IMGL)
-        for (int k = t0; k < H.image_total - img0; k += tstep) img[k] = A.image[img0 + k];
+        for (int k = t0; k < coop_image_doubles(H, NC) && img0 + k < H.image_total; k += tstep) img[k] = A.image[img0 + k];
     for (int k = t0; k < blocks * 8 * GROUP; k += tstep) {
         const int blk = k / (8 * GROUP), rest = k % (8 * GROUP);
         tk[k] = A.rowc[(long long)blk * ROWC * GROUP + rest];       // constants 0 .. 7 of the block's 16 rows
@@ -1677,7 +1683,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
     const CoopOff O = coop_offsets(H, NC);
     double *W = lds + coop_shared_doubles(H, IMGL, NC) + (long long)(wave_in_block * gpw + (wr ? grp : 0)) * coop_inst_doubles(H, NC);
     double *Cp = W + ((O.total + 1) & ~1);
-    CoopCtx c{A, H, O, IMGL ? img - img0 : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, LPI, i, valid, wr};
+    CoopCtx c{A, H, O, IMGL ? img - img0 : A.image + i * A.image_stride, W, Cp, tk, ti, lig, grp, LPI, coop_reads_sparse(H, NC), i, valid, wr};
 #ifdef ACME_COOP_TIMING
     CoopTimer tmr{};
     tmr.mark = (long long)__builtin_readcyclecounter();
@@ -1742,7 +1748,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             // p = dq x + eq u  (src/ACME.jl:678-683; a first sub-problem has no fqprev term)
             for (int r = lig; r < s.np; r += LPI) {
                 double acc;
-                if (H.ell) {
+                if (c.ell) {
                     acc = coop_ell_dot(c.M, s.e_dq, r, W + c.O.x, 0.0);
                     acc = coop_ell_dot(c.M, s.e_eq, r, un, acc);
                 } else {
@@ -1786,7 +1792,7 @@ template <bool IMGL, int NC> ACME_DEV void coop_main(const GArgs &A, double *lds
             const bool isx = rho < H.nx;
             const int r = isx ? rho : rho - H.nx, ldm = isx ? H.nx : H.ny;
             double acc;
-            if (H.ell) {
+            if (c.ell) {
                 acc = coop_ell_dot(c.M, H.e_ax, rho, W + c.O.x, c.M[H.o_xy0 + rho]);
                 acc = coop_ell_dot(c.M, H.e_bu, rho, un, acc);
                 acc = coop_ell_dot(c.M, H.e_cz, rho, W + c.O.z, acc);

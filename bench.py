@@ -449,6 +449,47 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3, with_cpu=Tr
             "y_abs_sum": float(torch.nan_to_num(y).abs().sum())}
 
 
+def mid_size_leg(local_rank, dev, sizes=(24, 32, 34, 48, 64), n=8192, steps=2, warmup=2):
+    """config.mid_size (never `value`): the mid-size kernel (csrc/acme_coop.h) over the range the reference's LU is written for
+    (src/solvers.jl:53-54, "sizes up to about 60 x 60") -- the clipper chain of clipper_chain_20 with 12 ... 32 stages, ONE
+    undecomposed sub-problem of 24 ... 64 unknowns, 8 192 instances, a twentieth of a second per step: 17 ... 32 unknowns
+    run with the Jacobian's rows in registers, 33 ... 64 on one matrix per instance in LDS with one instance per wave."""
+    import torch
+    from fractions import Fraction
+    from acme_jl_amd import examples
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    T = FS // 20
+    amp = 10.0 ** (-2 + 2.7 * np.arange(n) / max(n - 1, 1))
+    out = []
+    for nn in sizes:
+        try:
+            model = DiscreteModel(examples.clipper_chain(nn // 2), Fraction(1, FS), CachingHomotopySolver, decompose_nonlinearity=False)
+            runner = ModelRunner(model, n, device=local_rank)
+            u = make_u(torch, dev, model, None, amp, n, T)
+            y = torch.empty((n, T, model.ny), dtype=torch.float64, device=dev)
+            for _ in range(warmup):
+                runner.run_torch(u, y)
+            torch.cuda.synchronize()
+            runner.reset_report()
+            runner.kernel_time(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                runner.run_torch(u, y)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            ms_total, launches = runner.kernel_time()
+            ra = runner.report_arrays()
+            out.append({"unknowns": nn, "instances": n, "samples_per_step": T, "steps": steps, "warmup": warmup, "kernel_family": runner.kernel_family(),
+                        "value": n * T * steps / elapsed, "kernel_ms": ms_total / max(launches, 1),
+                        "newton_iters_per_sample": float(ra["iters_total"].sum()) / (n * T * steps), "n_warn": float(ra["n_warn"].sum()),
+                        "y_abs_sum": float(torch.nan_to_num(y).abs().sum())})
+            del runner, u, y
+        except Exception as e:      # (the headline line must come out whatever happens here)
+            out.append({"unknowns": nn, "error": repr(e)})
+    return out
+
+
 def waves_per_simd(runner, n, n_simd=1024):
     """resident wavefronts per SIMD this batch puts on the chip (256 CUs x 4 SIMDs): 16 lanes per instance in the tuned and
     the mid-size kernels (4 instances per wave), one lane per instance in the generic kernel; the lane-per-instance kernel
@@ -597,6 +638,15 @@ def host_buffer_leg(runner, u, N, T, model):
         t_const = min(call_const() for _ in range(2))
         out.update(const_rows=const_rows, const_rows_ms=1e3 * t_const, const_rows_value=N * T / t_const, const_rows_bytes_in=int(uv.nbytes + uc.nbytes),
                    const_rows_y_abs_sum=float(np.abs(np.nan_to_num(yc)).sum()))
+        # ... and for a caller who keeps and reuses its arrays (acme_batch_set_host_retention: u_var and y page-locked once)
+        runner.set_host_retention(True)
+        try:
+            t_lock = call_const()
+            t_kept = min(call_const() for _ in range(2))
+            out.update(const_rows_retained_first_ms=1e3 * t_lock, const_rows_retained_ms=1e3 * t_kept, const_rows_retained_value=N * T / t_kept)
+        finally:
+            runner.release_host_buffers()
+            runner.set_host_retention(False)
     out.update(inplace_ms=1e3 * extra["inplace"], inplace_value=N * T / extra["inplace"],
                staged_ms=1e3 * extra["staged"], staged_value=N * T / extra["staged"],
                pageable_ms=1e3 * t_page, pageable_value=N * T / t_page,
@@ -806,6 +856,9 @@ def main():
                 others.append(other_workload_leg(wl, local_rank, dev))
             except Exception as e:      # (the headline line must come out whatever happens here)
                 others.append({"workload": wl, "error": repr(e)})
+    mid = None
+    if world == 1 and args.workload == "superover_grid" and not args.no_other_workloads:
+        mid = mid_size_leg(local_rank, dev)
     literal = saturation = None
     if world == 1 and args.workload == "superover_grid" and not args.no_other_workloads and not args.no_literal_grid:
         try:
@@ -865,6 +918,7 @@ def main():
                 "value_host_buffers": host["steady_value"] if host else None,
                 "host_buffers": host,
                 "other_workloads": others,
+                "mid_size": mid,
                 "literal_grid": literal,
                 "saturation": saturation,
                 "grid_note": "`value` runs drive = i/32 (i = 0 ... 31): SURVEY 8(d) quotes linspace(0, 1, 32), whose last column "

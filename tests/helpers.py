@@ -183,11 +183,12 @@ def beyond_the_tuned_shapes():
             ("40-stage RC ladder", DiscreteModel(examples.rc_ladder(40), t, HS), u)]
 
 
-def mid_size_models(more=False):
+def mid_size_models(more=False, big=False):
     """(name, model, u[N, nu, T]) in the cooperative mid-size kernel's range (csrc/acme_coop.h): ONE sub-problem of 24 / 32
     unknowns -- two rows per lane, the second group of 16 rows full or half full -- and of 18 / 27: sizes that are not a
     multiple of four (the register instantiations carry whole groups of four columns, the last one padded), one of
-    them odd.  more: also 34 unknowns (beyond the register instantiations: three rows per lane, everything in LDS)."""
+    them odd.  more: also 34 unknowns (beyond the register instantiations: the matrix in LDS, one instance per wave); big: 47
+    and 64 as well."""
     from fractions import Fraction
     import circuits
     from acme_jl_amd.model import DiscreteModel
@@ -203,4 +204,7 @@ def mid_size_models(more=False):
               ("22 unknowns, ties", DiscreteModel(circuits.clipper_chain(11, symmetric=True), t, HS, decompose_nonlinearity=False), u)]
     if more:
         models.append(("34 unknowns", DiscreteModel(circuits.clipper_chain(17), t, HS, decompose_nonlinearity=False), u))
+    if big:          # (GPU tests: the largest sizes of the range)
+        models.append(("47 unknowns", DiscreteModel(circuits.clipper_chain(23, tail=True), t, HS, decompose_nonlinearity=False), u))
+        models.append(("64 unknowns", DiscreteModel(circuits.clipper_chain(32), t, HS, decompose_nonlinearity=False), u))
     return models

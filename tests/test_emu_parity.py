@@ -876,19 +876,40 @@ def test_emulated_mid_size_kernel(emu_lib, monkeypatch):
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
-    for name, m, u in mid_size_models() + beyond_the_tuned_shapes()[:1]:
+    for name, m, u in mid_size_models(more=True) + beyond_the_tuned_shapes()[:1]:
         for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
             m.solver = solver
             yref, its = oracle_run(m, u, cache_limit=lim)
             outs = {}
+            # the threshold path on a matrix in LDS (what 33 ... 64 unknowns run: one instance per wave, one row per lane;
+            # ACME_COOP_REG=0 sends 17 ... 32 unknowns there too, with 16 lanes per instance; ACME_COOP_WAVE64 = 1 / 0 pins the
+            # lanes per instance), from the natural row order and from the reversed one -- which the first elimination
+            # cannot keep: the re-learning path (the reference's pivoting on the matrix in LDS) runs at once
+            for env in ({"ACME_COOP_REG": "0"}, {"ACME_COOP_REG": "0", "ACME_COOP_WAVE64": "1"}, {"ACME_COOP_REG": "0", "ACME_COOP_WAVE64": "0"},
+                        {"ACME_COOP_REG": "0", "ACME_COOP_ORDER": "reversed"},
+                        {"ACME_COOP_REG": "0", "ACME_COOP_WAVE64": "0", "ACME_COOP_ORDER": "reversed"}):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                r = ModelRunner(m, u.shape[0], lib=emu_lib)
+                assert r.kernel_family() == "coop", (name, env)
+                y = np.concatenate([r.run(u[:, :, :50]), r.run(u[:, :, 50:])], axis=2)
+                assert_close(y, yref, rtol=RTOL_SAME)
+                assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, env)
+                key = "lds64" if env.get("ACME_COOP_WAVE64") == "1" else "lds16" if env.get("ACME_COOP_WAVE64") == "0" else "lds"
+                if "ACME_COOP_ORDER" not in env:
+                    outs[key] = y
+                for k in env:
+                    monkeypatch.delenv(k)
+            # (16 or 64 lanes per instance: who computes a row differs, not what is computed)
+            assert np.array_equal(outs["lds16"], outs["lds64"]), name
             for variant in ("coop", "coop, private images", "coop, literal", "lane per instance"):
                 if variant == "lane per instance":
                     monkeypatch.setenv("ACME_COOP", "0")
                 else:
                     monkeypatch.delenv("ACME_COOP", raising=False)
                 # (17 ... 32 unknowns run the instantiations with the Jacobian's rows in registers: elimination in a learnt
-                # row order, |l| <= 8; ACME_COOP_LITERAL=1 selects the any-size instantiation -- the reference's pivoting,
-                # factors in LDS --, which 33 ... 64 unknowns always use)
+                # row order, |l| <= 8; 33 ... 64 the same scheme on a matrix in LDS; ACME_COOP_LITERAL=1 selects the any-size
+                # instantiation -- the reference's pivoting, factors in LDS)
                 if "literal" in variant:
                     monkeypatch.setenv("ACME_COOP_LITERAL", "1")
                 else:

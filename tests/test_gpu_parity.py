@@ -874,15 +874,16 @@ def test_host_arrays_may_be_freed_after_any_call(hip_lib):
 
 
 def test_mid_size_kernel(hip_lib, monkeypatch):
-    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 18 / 27 / 22 (ties) / 34 / 20 unknowns (what the reference's LU
+    """csrc/acme_coop.h on the GPU: one sub-problem of 24 / 32 / 18 / 27 / 22 (ties) / 34 / 47 / 64 / 20 unknowns (what the reference's LU
     "for sizes up to about 60 x 60" is for, src/solvers.jl:53-54), both solver stacks, a launch boundary, 70 instances (full
     waves and a ragged last one): the oracle's outputs (RTOL_SAME) and iteration totals.
     17 ... 32 unknowns run the register instantiations (elimination in a learnt row order, |l| <= 8: the a-13 deviation the
-    tuned kernels make) -- held to the oracle at RTOL_SAME with the oracle's iteration totals, to the same bits in every
-    launch shape (1, 2 and 4 instances per wave; waves per block; image in LDS or L2), for 1 / 2 / 3 / 17 instances, private
-    images and a run cut into single-sample launches.  ACME_COOP_LITERAL=1 selects the reference's pivoting literally (the
-    any-size instantiation, everything in LDS: what 33 ... 64 unknowns always run): in every launch shape the same bits, and
-    the lane-per-instance kernel's entry by entry."""
+    tuned kernels make), 33 ... 64 the same scheme on one matrix per instance in LDS, one instance per wave -- held to the
+    oracle at RTOL_SAME with the oracle's iteration totals, to the same bits in every launch shape (1, 2 and 4 instances per
+    wave; waves per block; image in LDS or L2), for 1 / 2 / 3 / 17 instances, private images and a run cut into single-sample
+    launches; the matrix-in-LDS path also for every size, with 16 and with 64 lanes per instance, from a row order it has to
+    re-learn at once.  ACME_COOP_LITERAL=1 selects the reference's pivoting literally (the any-size instantiation,
+    everything in LDS): in every launch shape the same bits, and the lane-per-instance kernel's entry by entry."""
     from acme_jl_amd.model import CachingHomotopySolver
     from acme_jl_amd.runner import ModelRunner
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes, mid_size_models
@@ -893,7 +894,7 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
         edges = (0,) + tuple(cuts) + (u.shape[2],)
         return np.concatenate([r.run(u[:, :, a:b]) for a, b in zip(edges, edges[1:])], axis=2)
 
-    for name, m, u5 in mid_size_models(more=True) + beyond_the_tuned_shapes()[:1]:
+    for name, m, u5 in mid_size_models(more=True, big=True) + beyond_the_tuned_shapes()[:1]:
         N, T = 70, u5.shape[2]
         u = np.logspace(-1.5, 0.6, N)[:, None, None] * u5[2:3] / np.abs(u5[2]).max()
         for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
@@ -928,6 +929,26 @@ def test_mid_size_kernel(hip_lib, monkeypatch):
                 assert np.array_equal(y, yl), (name, solver, "default path", shape)
             for k in pins:
                 monkeypatch.delenv(k)
+            # the threshold path on a matrix in LDS (what 33 ... 64 unknowns run by default, one instance per wave; ACME_COOP_REG=0
+            # sends the smaller ones there too): 16 or 64 lanes per instance, from the natural and from the reversed row order
+            # (re-learning at once), the oracle's outputs and iteration totals; who computes a row does not show in the bits
+            ylds = {}
+            for wave64 in ("0", "1"):
+                for order in ("natural", "reversed"):
+                    for k, v in (("ACME_COOP_REG", "0"), ("ACME_COOP_WAVE64", wave64), ("ACME_COOP_ORDER", order)):
+                        monkeypatch.setenv(k, v)
+                    rl = ModelRunner(m, N, lib=hip_lib)
+                    assert rl.kernel_family() == "coop"
+                    yl = split_run(rl, u)
+                    assert_close(yl, yref, rtol=RTOL_SAME)
+                    assert rl.report_arrays()["iters_total"].tolist() == its.tolist(), (name, solver, "matrix in LDS", wave64, order)
+                    ylds[wave64, order] = yl
+            for k in ("ACME_COOP_REG", "ACME_COOP_WAVE64", "ACME_COOP_ORDER"):
+                monkeypatch.delenv(k)
+            assert np.array_equal(ylds["0", "natural"], ylds["1", "natural"]), (name, solver, "16 / 64 lanes per instance")
+            assert np.array_equal(ylds["0", "reversed"], ylds["1", "reversed"]), (name, solver, "16 / 64 lanes per instance, reversed")
+            if m.subs[0].nn > 32:
+                assert np.array_equal(y, ylds["1", "natural"]), (name, solver, "default path = one instance per wave")
             # the reference's pivoting literally (the any-size instantiation): in every launch shape the same bits
             monkeypatch.setenv("ACME_COOP_LITERAL", "1")
             ylit = None
