@@ -30,7 +30,7 @@ constexpr int ROWC = 38;          // precomputed constants per residual row
 enum UnifiedRowConst { UR_SA = 24, UR_SB, UR_CA, UR_CB, UR_DA, UR_DB, UR_H, UR_SPARE,
                        UR_G0 = 32, UR_G1, UR_G2, UR_W0, UR_W1 };
 constexpr int ROWI = 8;           // ints per residual row: kind, erow, flags, tc[0..3], (spare)
-constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8, MAX_NSUB = 4;
+constexpr int MAX_NN = 16, MAX_NP = 16, MAX_NY = 16, MAX_NX = 32, MAX_NQ = 32, MAX_NU = 8, MAX_NSUB = 8;
 
 // residual-row kinds (element kind of the row's element; same numbering as the element
 // kinds of include/acme_hip.h, plus PAD for rows added by host-side shape padding)

@@ -67,7 +67,7 @@ struct CoopTimer { long long t[CT_N]; long long mark; };
 // 8.8 KB per instance at 20 unknowns instead of 15.9: 16 resident instances per compute unit instead of 8, a wave for
 // every SIMD.
 struct CoopOff {
-    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, dinv, total;
+    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, dinv, pm, total;
 };
 ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
     CoopOff o{};
@@ -91,6 +91,7 @@ ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
         o.llu = take(nn * o.ld);
         o.xb = take(nn);                             // (behind the matrix: the replay's batched reads may run a few doubles past its last row)
         o.dinv = take(nn);
+        o.pm = take(nn);                             // (one instance per wave: which far pairs of columns each step's pivot row held last time)
         o.tv = take(4 * nn);
         // Jp by residual ROW, whatever position holds it: np columns and one that stays zero (where the padding entries of the
         // rows' sparse forms point, GenSub::o_pcol) -- or just the kp entries per row of the sparse form (GenHeader::jp_sparse)
@@ -969,6 +970,80 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
 #endif
     COOP_T(c, CT_S_REST);
 }
+// The same step for ONE INSTANCE PER WAVE (one row per lane), as ONE round trip through LDS where the matrix keeps its
+// pattern from one factorisation to the next -- it does: the pattern is the circuit's.  Beside the four pairs next to the
+// pivot's and the right-hand side's, up to four more are read AHEAD: the pairs beyond those four that this step's pivot row
+// held LAST time (pred: a 64-bit mask per step, kept beside the matrix, CoopOff::pm).  Every load of the step is requested
+// before the first is waited for; whatever the pivot row holds that was not foreseen (a new row order, a first
+// factorisation) takes the slow way, a pair at a time, and is foreseen next time (seen).
+template <bool ODD>
+ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsigned long long pred, unsigned long long &seen) {
+    double *F = c.W + c.O.llu;
+    const int ld = c.O.ld, kc = k & ~1;
+    const double *prow = F + k * ld;
+    const bool real = c.lig < n;
+    double *row = F + (real ? c.lig : n - 1) * ld;          // (a lane beyond the matrix reads its last row, writes nothing)
+    const int g0 = kc / 2 + 1, g1 = n / 2;                // first and last pair of the update (g1: the right-hand side's)
+    const wv::pair_t pp = wv::ld2(prow + kc), own = wv::ld2(row + kc);
+    const bool in = c.lig >= g0 && c.lig <= g1;
+    const wv::pair_t sv = wv::ld2(prow + 2 * (in ? c.lig : g1));          // lane l looks at pair l of the pivot row
+    constexpr int NB = 4, NF = 4;
+    wv::pair_t bb[NB], ab[NB], bf[NF], af[NF];
+    const double *pb = prow + 2 * g0;          // (reads past the end of a row are harmless: the next row, or what lies behind the matrix)
+    double *rb = row + 2 * g0;
+    sfor<0, NB>([&](auto uc) ACME_LAMBDA {
+        constexpr int u = decltype(uc)::value;
+        bb[u] = wv::ld2(pb + 2 * u);
+        ab[u] = wv::ld2(rb + 2 * u);
+    });
+    const wv::pair_t br = wv::ld2(prow + 2 * g1), ar = wv::ld2(row + 2 * g1);
+    const unsigned long long near = (0xFull << g0) | (1ull << g1);
+    unsigned long long far = pred & ~near;
+    int gf[NF];
+    sfor<0, NF>([&](auto ic) ACME_LAMBDA {
+        constexpr int i = decltype(ic)::value;
+        gf[i] = far != 0ull ? __builtin_ctzll(far) : g1;          // (nothing foreseen: the right-hand side's pair once more, read only)
+        far &= far - 1ull;
+        bf[i] = wv::ld2(prow + 2 * gf[i]);
+        af[i] = wv::ld2(row + 2 * gf[i]);
+    });
+    const unsigned long long todo = wv::ballot(in && !(sv.lo == 0.0 && sv.hi == 0.0));          // (a NaN counts as something)
+    const double piv = ODD ? pp.hi : pp.lo;
+    const double inv = wv::recip(piv);
+    const bool below = real && c.lig > k;
+    const double m = below ? -(ODD ? own.hi : own.lo) * inv : 0.0;
+    vmx = fmax(vmx, fabs(m));
+    if (c.lig == k) c.W[c.O.dinv + k] = inv;
+    unsigned long long rest = todo & ~near;
+    seen = rest;
+    if (wv::ballot(m != 0.0) == 0ull) return;          // (no row below holds anything in column k)
+    if (real) {
+        // column k of the rows below: minus the multiplier; the rows above (and the pivot's) keep what they hold
+        if (ODD) wv::st2(row + kc, own.lo, below ? m : own.hi);
+        else wv::st2(row + kc, below ? m : own.lo, fma(m, pp.hi, own.hi));
+    }
+    sfor<0, NB>([&](auto uc) ACME_LAMBDA {
+        constexpr int u = decltype(uc)::value;
+        if (g0 + u <= g1 && (((todo >> (g0 + u)) & 1ull) != 0ull || g0 + u == g1))
+            if (real) wv::st2(rb + 2 * u, fma(m, bb[u].lo, ab[u].lo), fma(m, bb[u].hi, ab[u].hi));
+    });
+    if (g0 + NB <= g1)
+        if (real) wv::st2(row + 2 * g1, fma(m, br.lo, ar.lo), fma(m, br.hi, ar.hi));
+    sfor<0, NF>([&](auto ic) ACME_LAMBDA {
+        constexpr int i = decltype(ic)::value;
+        if (gf[i] != g1 && ((rest >> gf[i]) & 1ull) != 0ull) {
+            if (real) wv::st2(row + 2 * gf[i], fma(m, bf[i].lo, af[i].lo), fma(m, bf[i].hi, af[i].hi));
+            rest &= ~(1ull << gf[i]);
+        }
+    });
+    while (rest != 0ull) {          // what was not foreseen
+        const int g = __builtin_ctzll(rest);
+        rest &= rest - 1ull;
+        const wv::pair_t b = wv::ld2(prow + 2 * g), a = wv::ld2(row + 2 * g);
+        if (real) wv::st2(row + 2 * g, fma(m, b.lo, a.lo), fma(m, b.hi, a.hi));
+    }
+}
+
 // The triangular sweeps on x in registers (slot sl of the lane: position lig + 16 sl), the factors read from the lane's rows
 // in runs of eight columns, x_k broadcast by DPP.
 //   forward:  x_p += l_pk x_k  for p > k  (l: minus the multiplier, as stored), k ascending
@@ -1034,6 +1109,25 @@ template <int NS, int LPI> ACME_DEV void coop_lds_backward(int lig, int n, doubl
 template <int NS, int LPI>
 ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS]) {
     double vmx = 0.0;
+    if constexpr (LPI == 64) {
+        // (the masks of foreseen pairs: step k's is requested a step ahead, rewritten where the step saw something else)
+        unsigned long long *Pm = reinterpret_cast<unsigned long long *>(c.W + c.O.pm);
+        unsigned long long nxt = Pm[0];
+        for (int k = 0; k < n; k += 2) {
+            unsigned long long pred = wv::first64(nxt), seen;
+            nxt = Pm[k + 1 < n ? k + 1 : k];
+            coop_lu_w64_step<false>(c, n, k, vmx, pred, seen);
+            if (seen != pred && c.lig == 0) Pm[k] = seen;
+            wv::lds_order();          // (a step reads what the step before wrote: the DS pipeline keeps a wave's program order)
+            if (k + 1 < n) {
+                pred = wv::first64(nxt);
+                nxt = Pm[k + 2 < n ? k + 2 : k];
+                coop_lu_w64_step<true>(c, n, k + 1, vmx, pred, seen);
+                if (seen != pred && c.lig == 0) Pm[k + 1] = seen;
+                wv::lds_order();
+            }
+        }
+    } else
     for (int k = 0; k < n; k += 2) {
         coop_lu_lds_step<NS, false, LPI>(c, n, k, vmx);
         wv::lds_order();          // (a step reads what the step before wrote: the DS pipeline keeps a wave's program order)

@@ -130,7 +130,8 @@ constexpr int shape_part(int index) {
     constexpr int table[] = {0 /* diode clipper */, 1 /* superover, fixed pots */, 2 /* superover, pots as inputs */,
                              0 /* birdie, fixed vol */, 1 /* birdie, vol as input */, 2 /* linear */, 3 /* generic small */,
                              3 /* generic medium */, 3 /* generic large */, 5 /* decomposed small */, 4 /* decomposed medium */,
-                             0 /* superover, pots as inputs, condensed -- the headline kernel: the default scheduler again (round 5, one solver copy: 275.1 ms against 278.6 with max-ilp; round 4's two-copy kernel gained 0.6 % with max-ilp) */};
+                             0 /* superover, pots as inputs, condensed -- the headline kernel: the default scheduler again (round 5, one solver copy: 275.1 ms against 278.6 with max-ilp; round 4's two-copy kernel gained 0.6 % with max-ilp) */,
+                             2 /* decomposed, up to 8 small sub-problems */};
     return index < (int)(sizeof(table) / sizeof(table[0])) ? table[index] : index % ACME_NPARTS;
 }
 bool acme_shape_fns_part0(int index, ShapeFns *out);

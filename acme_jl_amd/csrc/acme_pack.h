@@ -455,7 +455,7 @@ inline bool pack_model(const HostModel &m_in, Packed &P, std::string &err, const
     d.nx = m.nx; d.nu = m.nu; d.ny = m.ny;
     d.nsub = (int)m.subs.size();
     if (d.nsub > MAX_NSUB) {
-        err = "more than 4 nonlinear sub-problems are not supported by the GPU path; derive the model with "
+        err = "more than 8 nonlinear sub-problems are not supported by the GPU path; derive the model with "
               "decompose_nonlinearity=false";
         return false;
     }

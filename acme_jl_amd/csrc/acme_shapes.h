@@ -39,6 +39,7 @@
     X(16, 32, 16, 32, 8, 8, 1, 1, 0)  /* generic large  (all element kinds)                */ \
     X( 4, 12,  4, 16, 4, 4, 1, 4, 0)  /* decomposed nonlinearity: up to 4 small sub-problems */ \
     X( 8, 24,  8, 16, 4, 4, 1, 4, 0)  /* decomposed nonlinearity: up to 4 medium sub-problems */ \
-    X(13, 29, 11, 11, 4, 1, 0, 1, 6)  /* superover, pots as inputs: the 6 potentiometer rows condensed (the HEADLINE kernel) */
+    X(13, 29, 11, 11, 4, 1, 0, 1, 6)  /* superover, pots as inputs: the 6 potentiometer rows condensed (the HEADLINE kernel) */ \
+    X( 4, 12,  4, 16, 4, 4, 1, 8, 0)  /* decomposed nonlinearity: up to 8 small sub-problems */
 // clang-format on
 #endif

@@ -425,6 +425,12 @@ template <int K> ACME_DEV double lane64(double v) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), K);
     return __hiloint2double(hi, lo);
 }
+// a 64-bit value every lane holds alike, as a wave-uniform (scalar) value: the first lane's
+ACME_DEV unsigned long long first64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 ACME_DEV double allmin16(double v) {
     v = fmin(v, ror16<8>(v));
     v = fmin(v, ror16<4>(v));

@@ -168,7 +168,7 @@ def moving_pot_inputs(N, T, seed=5):
 
 
 def beyond_the_tuned_shapes():
-    """(name, model, u[N, nu, T]) for models no tuned kernel shape holds -- 20 unknowns in one sub-problem, six
+    """(name, model, u[N, nu, T]) for models no tuned kernel shape holds -- 20 unknowns in one sub-problem, nine
     nonlinear sub-problems, 40 states: the run-time-sized kernels take them (one sub-problem of up to 64 unknowns, or none:
     the cooperative mid-size kernel acme_coop.h; anything else: the lane-per-instance kernel acme_generic.h)."""
     from fractions import Fraction
@@ -179,7 +179,7 @@ def beyond_the_tuned_shapes():
     amp = np.array([0.2, 1.0, 3.0])
     u = amp[:, None, None] * sine(200)[None, None, :]
     return [("20 unknowns", DiscreteModel(circuits.clipper_chain(10), t, HS, decompose_nonlinearity=False), u),
-            ("6 sub-problems", DiscreteModel(circuits.buffered_clipper_chain(6), t, HS), u),
+            ("9 sub-problems", DiscreteModel(circuits.buffered_clipper_chain(9), t, HS), u),
             ("40-stage RC ladder", DiscreteModel(examples.rc_ladder(40), t, HS), u)]
 
 

@@ -702,14 +702,14 @@ def test_emulated_host_buffer_pipelines_agree(emu_lib, monkeypatch):
 
 
 def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):
-    """Models beyond every tuned kernel shape (20 unknowns, 6 sub-problems, 40 states) run in the generic
+    """Models beyond every tuned kernel shape (20 unknowns, 9 sub-problems, 40 states) run in the generic
     lane-per-instance kernel and walk the oracle's path (identical iteration totals, outputs to rounding), on both
     solver stacks and across a launch boundary; the same kernel, forced onto the BASELINE models (ACME_GENERIC=1),
     agrees with the oracle as well, and its solve / Jacobian / state entry points with the tuned kernels'."""
     from acme_jl_amd.model import CachingHomotopySolver
     from helpers import HS, RTOL_SAME, beyond_the_tuned_shapes
     for name, m, u in beyond_the_tuned_shapes():
-        assert max([s.nn for s in m.subs] + [0]) > 16 or len(m.subs) > 4 or m.nx > 32, name
+        assert max([s.nn for s in m.subs] + [0]) > 16 or len(m.subs) > 8 or m.nx > 32, name
         for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
             m.solver = solver
             r = emu_runner(emu_lib, m, u.shape[0])
@@ -743,6 +743,27 @@ def test_emulated_generic_kernel_never_refuses(emu_lib, monkeypatch):
     for a, b in zip(got["1"], got["0"]):
         b = np.asarray(b, dtype=float)
         np.testing.assert_allclose(np.asarray(a, dtype=float), b, rtol=1e-9, atol=1e-12 + 1e-12 * np.abs(b).max())
+
+
+def test_emulated_up_to_eight_sub_problems(emu_lib):
+    """Five to eight nonlinear sub-problems (src/ACME.jl:675-697 loops over however many nldecompose! left) run on a tuned
+    16-lane shape -- not in the lane-per-instance generic kernel, as up to round 5: the oracle's outputs and iteration
+    totals on both solver stacks, across a launch boundary."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from helpers import HS, RTOL_SAME, sine
+    u = np.array([0.2, 1.0, 3.0])[:, None, None] * sine(160)[None, None, :]
+    for stages in (5, 8):
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m = DiscreteModel(circuits.buffered_clipper_chain(stages), Fraction(1, 44100), solver)
+            assert len(m.subs) == stages
+            r = emu_runner(emu_lib, m, u.shape[0])
+            assert r.kernel_family() == "tuned", stages
+            y = np.concatenate([r.run(u[:, :, :70]), r.run(u[:, :, 70:])], axis=2)
+            yref, its = oracle_run(m, u, cache_limit=lim)
+            assert_close(y, yref, rtol=RTOL_SAME)
+            assert r.report_arrays()["iters_total"].tolist() == its.tolist(), (stages, solver)
 
 
 def test_emulated_isolation_of_slow_instances(emu_lib):

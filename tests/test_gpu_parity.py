@@ -770,8 +770,32 @@ def test_host_buffer_paths_agree_bit_for_bit(hip_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_up_to_eight_sub_problems(hip_lib):
+    """Five to eight nonlinear sub-problems on the GPU: a tuned 16-lane shape (round 6; the lane-per-instance generic kernel
+    before), the oracle's outputs and iteration totals on both solver stacks, across a launch boundary, 200 instances."""
+    from fractions import Fraction
+    import circuits
+    from acme_jl_amd.model import CachingHomotopySolver, DiscreteModel
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL_SAME
+    N, T = 200, 160
+    u = np.logspace(-1, 0.5, N)[:, None, None] * sine(T)[None, None, :]
+    spot = [0, 57, 123, 199]
+    for stages in (5, 6, 8):
+        for solver, lim in ((HS, None), (CachingHomotopySolver, 16)):
+            m = DiscreteModel(circuits.buffered_clipper_chain(stages), Fraction(1, 44100), solver)
+            r = ModelRunner(m, N, lib=hip_lib)
+            assert r.kernel_family() == "tuned", stages
+            y = np.concatenate([r.run(u[:, :, :70]), r.run(u[:, :, 70:])], axis=2)
+            yref, its = oracle_run(m, u[spot], cache_limit=lim)
+            err = assert_close(y[spot], yref, rtol=RTOL_SAME)
+            assert r.report_arrays()["iters_total"][spot].tolist() == its.tolist(), (stages, solver)
+            print(f"{stages} sub-problems, {solver}: shape {r.kernel_shape()}, rel err {err:.2e}")
+
+
+@pytest.mark.gpu
 def test_generic_kernel_never_refuses(hip_lib, monkeypatch):
-    """Models no tuned kernel shape holds -- 20 unknowns in one sub-problem, six nonlinear sub-problems, a 40-state
+    """Models no tuned kernel shape holds -- 20 unknowns in one sub-problem, nine nonlinear sub-problems, a 40-state
     ladder -- run in the generic lane-per-instance kernel and follow the oracle (RTOL_SAME, identical iteration
     totals), on both solver stacks, across a launch boundary, with 200 instances; forced onto a BASELINE model
     (ACME_GENERIC=1) it agrees with the oracle too."""

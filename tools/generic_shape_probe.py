@@ -28,7 +28,10 @@ cases = [
     ("buffered clipper chain, 4 stages (nsub 4)", DiscreteModel(circuits.buffered_clipper_chain(4), t, CachingHomotopySolver)),
     # beyond the tuned shapes: the generic lane-per-instance kernel (acme_generic.h)
     ("clipper chain, 10 stages (nn 20) [generic]", DiscreteModel(circuits.clipper_chain(10), t, CachingHomotopySolver, decompose_nonlinearity=False)),
-    ("buffered clipper chain, 6 stages (nsub 6) [generic]", DiscreteModel(circuits.buffered_clipper_chain(6), t, CachingHomotopySolver)),
+    # (up to 8 sub-problems: a tuned shape since round 6; 9 and more: the lane-per-instance generic kernel)
+    ("buffered clipper chain, 6 stages (nsub 6)", DiscreteModel(circuits.buffered_clipper_chain(6), t, CachingHomotopySolver)),
+    ("buffered clipper chain, 8 stages (nsub 8)", DiscreteModel(circuits.buffered_clipper_chain(8), t, CachingHomotopySolver)),
+    ("buffered clipper chain, 9 stages (nsub 9) [generic]", DiscreteModel(circuits.buffered_clipper_chain(9), t, CachingHomotopySolver)),
     # the cooperative mid-size kernel's range (acme_coop.h; ACME_COOP=0: the lane-per-instance kernel)
     ("clipper chain, 12 stages (nn 24) [generic]", DiscreteModel(circuits.clipper_chain(12), t, CachingHomotopySolver, decompose_nonlinearity=False)),
     ("clipper chain, 16 stages (nn 32) [generic]", DiscreteModel(circuits.clipper_chain(16), t, CachingHomotopySolver, decompose_nonlinearity=False)),
