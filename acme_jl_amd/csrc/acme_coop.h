@@ -971,11 +971,13 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
     COOP_T(c, CT_S_REST);
 }
 // The same step for ONE INSTANCE PER WAVE (one row per lane), as ONE round trip through LDS where the matrix keeps its
-// pattern from one factorisation to the next -- it does: the pattern is the circuit's.  Beside the four pairs next to the
-// pivot's and the right-hand side's, up to four more are read AHEAD: the pairs beyond those four that this step's pivot row
-// held LAST time (pred: a 64-bit mask per step, kept beside the matrix, CoopOff::pm).  Every load of the step is requested
-// before the first is waited for; whatever the pivot row holds that was not foreseen (a new row order, a first
-// factorisation) takes the slow way, a pair at a time, and is foreseen next time (seen).
+// pattern from one factorisation to the next -- it does: the pattern is the circuit's.  Beside the right-hand side's pair the
+// step reads AHEAD the pairs of columns this step's pivot row held LAST time (pred: a 64-bit mask per step, kept beside the
+// matrix, CoopOff::pm; up to six of them), of the pivot row and of the lane's own row -- and nothing else: with eight waves
+// to a compute unit it is the LDS pipe the steps queue for (a 16-byte read of a wave takes it 4 cycles, a store 13), so a
+// pair that holds nothing is not read on the off chance.  Every load of the step is requested before the first is waited
+// for; whatever the pivot row holds that was not foreseen (a new row order, the first factorisation of a launch) takes the
+// slow way, a pair at a time, and is foreseen next time (seen).
 template <bool ODD>
 ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsigned long long pred, unsigned long long &seen) {
     double *F = c.W + c.O.llu;
@@ -984,63 +986,69 @@ ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsi
     const bool real = c.lig < n;
     double *row = F + (real ? c.lig : n - 1) * ld;          // (a lane beyond the matrix reads its last row, writes nothing)
     const int g0 = kc / 2 + 1, g1 = n / 2;                // first and last pair of the update (g1: the right-hand side's)
+    const bool rhs_apart = g0 <= g1;                      // (n odd, last step: the right-hand side shares the pivot's pair)
     const wv::pair_t pp = wv::ld2(prow + kc), own = wv::ld2(row + kc);
-    const bool in = c.lig >= g0 && c.lig <= g1;
+    const bool in = c.lig >= g0 && c.lig < g1;
     const wv::pair_t sv = wv::ld2(prow + 2 * (in ? c.lig : g1));          // lane l looks at pair l of the pivot row
-    constexpr int NB = 4, NF = 4;
-    wv::pair_t bb[NB], ab[NB], bf[NF], af[NF];
-    const double *pb = prow + 2 * g0;          // (reads past the end of a row are harmless: the next row, or what lies behind the matrix)
-    double *rb = row + 2 * g0;
-    sfor<0, NB>([&](auto uc) ACME_LAMBDA {
-        constexpr int u = decltype(uc)::value;
-        bb[u] = wv::ld2(pb + 2 * u);
-        ab[u] = wv::ld2(rb + 2 * u);
-    });
     const wv::pair_t br = wv::ld2(prow + 2 * g1), ar = wv::ld2(row + 2 * g1);
-    const unsigned long long near = (0xFull << g0) | (1ull << g1);
-    unsigned long long far = pred & ~near;
+    constexpr int NF = 6;
+    wv::pair_t bf[NF], af[NF];
     int gf[NF];
-    sfor<0, NF>([&](auto ic) ACME_LAMBDA {
-        constexpr int i = decltype(ic)::value;
-        gf[i] = far != 0ull ? __builtin_ctzll(far) : g1;          // (nothing foreseen: the right-hand side's pair once more, read only)
-        far &= far - 1ull;
-        bf[i] = wv::ld2(prow + 2 * gf[i]);
-        af[i] = wv::ld2(row + 2 * gf[i]);
-    });
-    const unsigned long long todo = wv::ballot(in && !(sv.lo == 0.0 && sv.hi == 0.0));          // (a NaN counts as something)
+    // up to NF pairs of `from` requested (pivot row and own row); what was taken leaves `from`
+    auto request = [&](unsigned long long &from) ACME_LAMBDA {
+        sfor<0, NF>([&](auto ic) ACME_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            gf[i] = -1;
+            if (from != 0ull) {
+                gf[i] = __builtin_ctzll(from);
+                from &= from - 1ull;
+                bf[i] = wv::ld2(prow + 2 * gf[i]);
+                af[i] = wv::ld2(row + 2 * gf[i]);
+            }
+        });
+    };
+    unsigned long long spec = pred;
+    request(spec);
+    COOP_T(c, CT_S_SCAN);
+    unsigned long long rest = wv::ballot(in && !(sv.lo == 0.0 && sv.hi == 0.0));          // (a NaN counts as something)
+    COOP_T(c, CT_S_HEAD);
+    seen = rest;
     const double piv = ODD ? pp.hi : pp.lo;
     const double inv = wv::recip(piv);
     const bool below = real && c.lig > k;
     const double m = below ? -(ODD ? own.hi : own.lo) * inv : 0.0;
     vmx = fmax(vmx, fabs(m));
     if (c.lig == k) c.W[c.O.dinv + k] = inv;
-    unsigned long long rest = todo & ~near;
-    seen = rest;
+#ifdef ACME_COOP_TIMING
+    c.tm->t[CT_S_STEPS] += 1;
+#endif
+    COOP_T(c, CT_S_BAND);
     if (wv::ballot(m != 0.0) == 0ull) return;          // (no row below holds anything in column k)
     if (real) {
         // column k of the rows below: minus the multiplier; the rows above (and the pivot's) keep what they hold
         if (ODD) wv::st2(row + kc, own.lo, below ? m : own.hi);
         else wv::st2(row + kc, below ? m : own.lo, fma(m, pp.hi, own.hi));
+        if (rhs_apart) wv::st2(row + 2 * g1, fma(m, br.lo, ar.lo), fma(m, br.hi, ar.hi));
     }
-    sfor<0, NB>([&](auto uc) ACME_LAMBDA {
-        constexpr int u = decltype(uc)::value;
-        if (g0 + u <= g1 && (((todo >> (g0 + u)) & 1ull) != 0ull || g0 + u == g1))
-            if (real) wv::st2(rb + 2 * u, fma(m, bb[u].lo, ab[u].lo), fma(m, bb[u].hi, ab[u].hi));
-    });
-    if (g0 + NB <= g1)
-        if (real) wv::st2(row + 2 * g1, fma(m, br.lo, ar.lo), fma(m, br.hi, ar.hi));
-    sfor<0, NF>([&](auto ic) ACME_LAMBDA {
-        constexpr int i = decltype(ic)::value;
-        if (gf[i] != g1 && ((rest >> gf[i]) & 1ull) != 0ull) {
-            if (real) wv::st2(row + 2 * gf[i], fma(m, bf[i].lo, af[i].lo), fma(m, bf[i].hi, af[i].hi));
-            rest &= ~(1ull << gf[i]);
-        }
-    });
-    while (rest != 0ull) {          // what was not foreseen
-        const int g = __builtin_ctzll(rest);
-        rest &= rest - 1ull;
-        const wv::pair_t b = wv::ld2(prow + 2 * g), a = wv::ld2(row + 2 * g);
-        if (real) wv::st2(row + 2 * g, fma(m, b.lo, a.lo), fma(m, b.hi, a.hi));
+    // the requested pairs that the pivot row does hold are updated; `rest` keeps what is still to do
+    auto apply = [&]() ACME_LAMBDA {
+        sfor<0, NF>([&](auto ic) ACME_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            if (gf[i] >= 0 && ((rest >> gf[i]) & 1ull) != 0ull) {
+                if (real) wv::st2(row + 2 * gf[i], fma(m, bf[i].lo, af[i].lo), fma(m, bf[i].hi, af[i].hi));
+                rest &= ~(1ull << gf[i]);
+            }
+        });
+    };
+    apply();
+    COOP_T(c, CT_S_REST);
+    while (rest != 0ull) {          // what was not foreseen, or beyond the first six: NF pairs to a round trip
+#ifdef ACME_COOP_TIMING
+        c.tm->t[CT_S_CHUNKS] += 1;
+#endif
+        unsigned long long more = rest;
+        request(more);
+        apply();
     }
 }
 

@@ -20,8 +20,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 1102
 NAMES = ["set_p", "extrapolation (solve!)", "evaluate!", "setlhs! (LU)", "solve! + step", "accept (Jp, origin)", "cache lookup",
          "y / x update", "p = dq x + eq u", "rest", "(LU: pivot search | LDS matrix: rest of the steps)",
-         "(LU: pivot row hand-off, 1 / pivot | LDS matrix: factorisations [count])", "LDS step: loads + scan", "LDS step: 1 / pivot, column k",
-         "LDS step: pairs read ahead", "LDS step: other pairs", "LDS step: chunks [count]", "LDS steps [count]"]
+         "(LU: pivot row hand-off, 1 / pivot | LDS matrix: factorisations [count])", "LDS step: loads + scan (one instance per wave: requesting the loads)", "LDS step: 1 / pivot, column k (...: waiting for the scan)",
+         "LDS step: pairs read ahead (...: 1 / pivot, multipliers)", "LDS step: other pairs (...: stores)", "LDS step: chunks [count] (...: unforeseen pairs)", "LDS steps [count]"]
 m = DiscreteModel(circuits.clipper_chain(stages), Fraction(1, 44100), CachingHomotopySolver, decompose_nonlinearity=False)
 dev = torch.device("cuda", 0)
 sig = torch.sin(2 * np.pi * 1000 / 44100 * torch.arange(T, dtype=torch.float64, device=dev))
