@@ -61,13 +61,13 @@ def test_montecarlo_models_are_seeded_per_rank():
 
 def test_cpu_baseline_handles_every_workload_shape():
     """cpu_baseline with per-instance pots (superover grid), per-instance amplitudes (diode clipper) and
-    one common scalar amplitude (the Monte-Carlo workload, which once crashed here); the workload without a fixture (the
-    20-unknown clipper chain: its model is derived on the spot, also in the oracle's worker processes)."""
+    one common scalar amplitude (the Monte-Carlo workload, which once crashed here); the workloads without a fixture file (the
+    clipper chains: their model is derived on the spot, also in the oracle's worker processes)."""
     import bench
     from helpers import HS, load
-    for workload, n in (("superover_grid", 256), ("diodeclipper_sweep", 64), ("superover_montecarlo", 64), ("clipper_chain_20", 64)):
+    for workload, n in (("superover_grid", 256), ("diodeclipper_sweep", 64), ("superover_montecarlo", 64), ("clipper_chain_20", 64), ("clipper_chain_34", 16)):
         fixture, pots, amp = bench.grid_inputs(workload, 0, 1, n, 64)
-        model = load(fixture) if fixture else bench.workload_model(workload, None, HS)
+        model = bench.workload_model(workload, fixture, HS) if fixture.startswith("chain:") else load(fixture)
         rec = bench.cpu_baseline(fixture, model, pots, amp, 64, per_core=1)
         assert rec["value"] > 0 and rec["kind"] == "port" and rec["iters_per_sample"] >= 1.0
 

@@ -77,7 +77,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     opt = lambda name, default: a[a.index(name) + 1] if name in a else default      # noqa: E731
     wl = opt("--workload", "superover_grid")
     n_def = {"diodeclipper_sweep": 4096, "birdie_grid": 2048}.get(wl, 8192)      # bench.py's defaults
-    t_def = 176400 if wl == "birdie_grid" else 4410 if wl == "clipper_chain_20" else 44100
+    t_def = 176400 if wl == "birdie_grid" else 4410 if wl.startswith("clipper_chain") else 44100
     try:        # what exactly ran: the traced run's own bench line (solver stack, kernel variant, its kernel_ms)
         line = json.loads(open(out + "/bench_line.json").read().strip().splitlines()[-1])
     except Exception:
