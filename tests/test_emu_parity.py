@@ -1148,3 +1148,37 @@ def test_emulated_per_instance_elements_and_condensed_shapes(emu_lib, monkeypatc
     r0 = ModelRunner(models[0], 3, lib=emu_lib, models=models)
     assert r0.kernel_variant()[0] == 0
     assert np.array_equal(r0.run(u), y)
+
+
+def test_emulated_mid_size_private_models_and_the_dense_fallback(emu_lib):
+    """The mid-size kernel on a matrix in LDS with one model PER INSTANCE (34 unknowns): every instance's image carries its own
+    sparse forms of the matrices with the batch's entries per row (csrc/acme_pack.h pack_generic `like`) -- instances whose
+    matrices differ in their VALUES follow the oracle run of their own model; and an instance whose model has a FULLER row than
+    the batch's sparse forms hold (an entry of fq where the batch model has none) switches the whole batch back to the dense
+    matrices (GenHeader::ell = 0): still the oracle's outputs and iteration totals, for every instance."""
+    import copy
+    from helpers import HS, RTOL_SAME, mid_size_models
+    name, m, u = [x for x in mid_size_models(more=True) if x[0] == "34 unknowns"][0]
+    m.solver = HS
+    u = u[:3]
+    variants = [m]
+    m1 = copy.deepcopy(m)                      # other values, the same pattern
+    m1.subs[0].q0 = m1.subs[0].q0 * 1.01
+    m1.c = m1.c * 0.99
+    m1.subs[0].fq = m1.subs[0].fq * 1.02
+    variants.append(m1)
+    m2 = copy.deepcopy(m)                      # ... and one more entry in a row of fq, of dq and of c
+    s2 = m2.subs[0]
+    r, c = [(r, c) for r in range(s2.nq) for c in range(s2.nn) if s2.fq[r, c] == 0.0 and np.count_nonzero(s2.fq[r]) == np.count_nonzero(s2.fq, axis=1).max()][0]
+    s2.fq[r, c] = 1e-3
+    variants.append(m2)
+    for models, what in ((variants[:2] + [m], "same pattern"), (variants, "a fuller row: dense fallback")):
+        rr = emu_runner(emu_lib, m, 3, models=models)
+        assert rr.kernel_family() == "coop", what
+        y = np.concatenate([rr.run(u[:, :, :50]), rr.run(u[:, :, 50:])], axis=2)
+        got = rr.report_arrays()["iters_total"].tolist()
+        for k, mk in enumerate(models):
+            yref, its = oracle_run(mk, u[k:k + 1])
+            assert_close(y[k:k + 1], yref, rtol=RTOL_SAME)
+            assert got[k] == its.tolist()[0], (what, k)
+    assert np.abs(y[0] - y[1]).max() > 1e-9

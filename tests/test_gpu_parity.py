@@ -770,6 +770,39 @@ def test_host_buffer_paths_agree_bit_for_bit(hip_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_mid_size_private_models_and_the_dense_fallback(hip_lib):
+    """tests/test_emu_parity.py::test_emulated_mid_size_private_models_and_the_dense_fallback on the GPU, 70 instances: one model
+    per instance on the matrix-in-LDS path (34 unknowns) -- models that differ in their values (each image carries its own sparse
+    forms), and a batch in which one model has a fuller row of fq than the sparse forms hold (the whole batch reads the dense
+    matrices then): every checked instance follows the oracle run of ITS model."""
+    import copy
+    from acme_jl_amd.runner import ModelRunner
+    from helpers import HS, RTOL_SAME, mid_size_models
+    name, m, u5 = [x for x in mid_size_models(more=True) if x[0] == "34 unknowns"][0]
+    m.solver = HS
+    N = 70
+    u = np.logspace(-1.5, 0.6, N)[:, None, None] * u5[2:3] / np.abs(u5[2]).max()
+    m1 = copy.deepcopy(m)
+    m1.subs[0].q0 = m1.subs[0].q0 * 1.01
+    m1.c = m1.c * 0.99
+    m1.subs[0].fq = m1.subs[0].fq * 1.02
+    m2 = copy.deepcopy(m)
+    s2 = m2.subs[0]
+    r, c = [(r, c) for r in range(s2.nq) for c in range(s2.nn) if s2.fq[r, c] == 0.0 and np.count_nonzero(s2.fq[r]) == np.count_nonzero(s2.fq, axis=1).max()][0]
+    s2.fq[r, c] = 1e-3
+    for pool, what in (((m, m1), "same pattern"), ((m, m1, m2), "a fuller row: dense fallback")):
+        models = [pool[k % len(pool)] for k in range(N)]
+        rr = ModelRunner(m, N, lib=hip_lib, models=models)
+        assert rr.kernel_family() == "coop", what
+        y = np.concatenate([rr.run(u[:, :, :50]), rr.run(u[:, :, 50:])], axis=2)
+        got = rr.report_arrays()["iters_total"].tolist()
+        for k in (0, 1, 2, 33, 34, 35, 67, 68, 69):
+            yref, its = oracle_run(models[k], u[k:k + 1])
+            assert_close(y[k:k + 1], yref, rtol=RTOL_SAME)
+            assert got[k] == its.tolist()[0], (what, k)
+
+
+@pytest.mark.gpu
 def test_up_to_eight_sub_problems(hip_lib):
     """Five to eight nonlinear sub-problems on the GPU: a tuned 16-lane shape (round 6; the lane-per-instance generic kernel
     before), the oracle's outputs and iteration totals on both solver stacks, across a launch boundary, 200 instances."""
