@@ -53,9 +53,12 @@ template <class S> static int lane_lds(bool caching) {
 // (this translation unit instantiates no kernel: the entry points come from the parts)
 template <class S> static KernelEntry make_entry(int index) {
     ShapeFns f;
-    if (!(acme_shape_fns_part0(index, &f) || acme_shape_fns_part1(index, &f) || acme_shape_fns_part2(index, &f) ||
-          acme_shape_fns_part3(index, &f) || acme_shape_fns_part4(index, &f) || acme_shape_fns_part5(index, &f)))
-        abort();
+    // (every part fills in what it holds of the shape: a shape's LOW-LDS variants can live in another unit than the rest)
+    bool any = false;
+    any |= acme_shape_fns_part0(index, &f); any |= acme_shape_fns_part1(index, &f); any |= acme_shape_fns_part2(index, &f);
+    any |= acme_shape_fns_part3(index, &f); any |= acme_shape_fns_part4(index, &f); any |= acme_shape_fns_part5(index, &f);
+    any |= acme_shape_fns_part6(index, &f); any |= acme_shape_fns_part7(index, &f);
+    if (!any || !f.lds.fn) abort();
     return KernelEntry{Dims{S::NN, S::NQ, S::NP, S::NX, S::NU, S::NY, S::RARE ? 1 : 0, S::NSUB, S::NL}, f.lds, f.low, f.fn_lane,
                        S::lds_doubles(false), S::lds_doubles(true), S::lds_doubles_low(), S::STATE, S::CACHEI,
                        S::lds_doubles(true, true) - S::lds_doubles(true, false), S::lds_doubles_low(true) - S::lds_doubles_low(false),

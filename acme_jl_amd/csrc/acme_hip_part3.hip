@@ -1,3 +1,3 @@
-// kernel translation unit 3 of 6: see acme_hip_part.inc
+// kernel translation unit 3 of 8: see acme_hip_part.inc
 #define ACME_PART 3
 #include "acme_hip_part.inc"

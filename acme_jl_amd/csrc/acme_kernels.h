@@ -108,19 +108,20 @@ template <class S> static int launch_lane_shape(const KArgs &A, unsigned grid, s
         return (int)hipErrorInvalidValue;
     }
 }
-template <class S> static ShapeFns make_shape_fns() {
-    ShapeFns f;
-    f.lds = make_fns<S, false>();
-    if constexpr (S::HAS_LOW) f.low = make_fns<S, true>();
-    if constexpr (LaneShape<S>::supported) f.fn_lane = (const void *)acme_lane_kernel<S>;
-    f.launch_lane = &launch_lane_shape<S>;
-    return f;
+// (a shape's kernels can be split over two translation units -- shape_part / shape_part_low below --: each fills in its half)
+template <class S, bool MAIN, bool LOWHALF> static void fill_shape_fns(ShapeFns &f) {
+    if constexpr (MAIN) {
+        f.lds = make_fns<S, false>();
+        if constexpr (LaneShape<S>::supported) f.fn_lane = (const void *)acme_lane_kernel<S>;
+        f.launch_lane = &launch_lane_shape<S>;
+    }
+    if constexpr (LOWHALF && S::HAS_LOW) f.low = make_fns<S, true>();
 }
 
 // The kernels are instantiated in ACME_NPARTS translation units (acme_hip_part<k>.hip: the shapes with
 // shape_part(number in ACME_SHAPES) == k), compiled in parallel: the run kernel of one shape alone is
 // 10 ... 30 thousand instructions.  Each part answers for its own shapes.
-constexpr int ACME_NPARTS = 6;
+constexpr int ACME_NPARTS = 8;
 // Which part a shape lives in.  Not only for build time: the parts are compiled with different instruction
 // schedulers (__graft_entry__.py: HIP_UNIT_FLAGS).  Part 0 -- the smallest models, whose lane-per-instance kernels
 // prefer the compiler's default scheduler (the diode clipper sweep loses 1.2 % with max-ilp); parts 1-5 with -amdgpu-sched-strategy=max-ilp (birdie +3.9 %, config 4 +1.4 %,
@@ -131,14 +132,19 @@ constexpr int shape_part(int index) {
                              0 /* birdie, fixed vol */, 1 /* birdie, vol as input */, 2 /* linear */, 3 /* generic small */,
                              3 /* generic medium */, 3 /* generic large */, 5 /* decomposed small */, 4 /* decomposed medium */,
                              0 /* superover, pots as inputs, condensed -- the headline kernel: the default scheduler again (round 5, one solver copy: 275.1 ms against 278.6 with max-ilp; round 4's two-copy kernel gained 0.6 % with max-ilp) */,
-                             2 /* decomposed, up to 8 small sub-problems */};
+                             6 /* decomposed, up to 8 small sub-problems: a unit of its own (five minutes of compile time) */};
     return index < (int)(sizeof(table) / sizeof(table[0])) ? table[index] : index % ACME_NPARTS;
 }
+// ... and the part that holds a shape's LOW-LDS variants: its own, except for the shape of up to 8 sub-problems -- eight
+// kernels of 7.4 minutes of compile time together -- whose LOW variants are the last unit's
+constexpr int shape_part_low(int index) { return index == 12 ? 7 : shape_part(index); }
 bool acme_shape_fns_part0(int index, ShapeFns *out);
 bool acme_shape_fns_part1(int index, ShapeFns *out);
 bool acme_shape_fns_part2(int index, ShapeFns *out);
 bool acme_shape_fns_part3(int index, ShapeFns *out);
 bool acme_shape_fns_part4(int index, ShapeFns *out);
 bool acme_shape_fns_part5(int index, ShapeFns *out);
+bool acme_shape_fns_part6(int index, ShapeFns *out);
+bool acme_shape_fns_part7(int index, ShapeFns *out);
 
 }  // namespace acme

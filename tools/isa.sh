@@ -8,7 +8,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=/tmp/isa_$tag
 mkdir -p $out && cd $out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -join-splitedges=1 -shared -save-temps -DACME_DEV_SHAPES${DEVSHAPE:+=$DEVSHAPE} "$@" \
-    $root/acme_jl_amd/csrc/acme_hip.hip $root/acme_jl_amd/csrc/acme_hip_part[0-5].hip -o $out/lib.so 2> $out/build.log || { tail -30 $out/build.log; exit 1; }
+    $root/acme_jl_amd/csrc/acme_hip.hip $root/acme_jl_amd/csrc/acme_hip_part[0-7].hip -o $out/lib.so 2> $out/build.log || { tail -30 $out/build.log; exit 1; }
 S=acme_hip_part0-hip-amdgcn-amd-amdhsa-gfx950.s      # (developer builds have ONE shape: number 0, i.e. part 0)
 grep -E "^\s+\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|name):" $S | paste - - - - - - | sed 's/\s\+/ /g'
 grep -E '^\s+[a-z_0-9]+ |^\.LBB' $S > code.s

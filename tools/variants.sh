@@ -11,7 +11,7 @@ if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     tmp=$(mktemp -d)
-    for tu in acme_hip acme_hip_part0 acme_hip_part1 acme_hip_part2 acme_hip_part3 acme_hip_part4 acme_hip_part5; do
+    for tu in acme_hip acme_hip_part0 acme_hip_part1 acme_hip_part2 acme_hip_part3 acme_hip_part4 acme_hip_part5 acme_hip_part6 acme_hip_part7; do
       unit=""      # the product's per-unit flags (__graft_entry__.py: HIP_UNIT_FLAGS); NOUNIT=1 builds every unit alike
       case $tu in acme_hip_part[12345]) [ -z "$NOUNIT" ] && unit="-mllvm -amdgpu-sched-strategy=${UNITSTRAT:-max-ilp}";; esac
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -join-splitedges=1 $unit $flags -c acme_jl_amd/csrc/$tu.hip -o $tmp/$tu.o &
