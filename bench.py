@@ -405,20 +405,17 @@ def other_workload_leg(workload, local_rank, dev, steps=2, warmup=3, with_cpu=Tr
         runner = ModelRunner(model, n, device=local_rank)
     u = make_u(torch, dev, model, pots, amp, n, T, fs)
     y = torch.empty((n, T, model.ny), dtype=torch.float64, device=dev)
+    # (a leg that follows a CPU-baseline leg finds the GPU at idle clocks, and three short warm-up steps do not always bring
+    # them back: half a second of unrelated work first -- the warm-up steps themselves stay what the profiles' are)
+    spin = torch.ones((2048, 2048), dtype=torch.float64, device=dev)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.5:
+        spin = (spin @ spin) * 0.0 + 1.0
+        torch.cuda.synchronize()
+    del spin
     for _ in range(warmup):
         runner.run_torch(u, y)
     torch.cuda.synchronize()
-    # (a leg that follows a CPU-baseline leg finds the GPU at idle clocks: up to four more untimed steps, until two in a row
-    # take the same time to 1.5 % -- the steady state the timed steps are meant to show)
-    prev = None
-    for _ in range(4):
-        runner.kernel_time(reset=True)
-        runner.run_torch(u, y)
-        torch.cuda.synchronize()
-        ms1 = runner.kernel_time()[0]
-        if prev is not None and abs(ms1 - prev) <= 0.015 * prev:
-            break
-        prev = ms1
     runner.reset_report()
     runner.kernel_time(reset=True)
     t0 = time.perf_counter()
