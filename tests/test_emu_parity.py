@@ -1182,3 +1182,35 @@ def test_emulated_mid_size_private_models_and_the_dense_fallback(emu_lib):
             assert_close(y[k:k + 1], yref, rtol=RTOL_SAME)
             assert got[k] == its.tolist()[0], (what, k)
     assert np.abs(y[0] - y[1]).max() > 1e-9
+
+
+def test_emulated_mid_size_non_finite_input(emu_lib, monkeypatch):
+    """A non-finite input sample in one instance of a 34-unknown batch (src/ACME.jl:688-694: the reference throws; here that
+    instance stops and reports the sample, its neighbours are unaffected): the mid-size kernel's instantiations -- one
+    instance per wave and 16 lanes per instance on a matrix in LDS, the literal one -- agree with the lane-per-instance
+    generic kernel in the report, the iteration totals (the failing solve's included) and every finite output."""
+    import warnings
+    from helpers import HS, mid_size_models
+    name, m, u = [x for x in mid_size_models(more=True) if x[0] == "34 unknowns"][0]
+    m.solver = HS
+    u = u[:3, :, :80].copy()
+    u[1, 0, 40] = np.inf
+    got = {}
+    for tag, env in (("lane per instance", {"ACME_COOP": "0"}), ("one instance per wave", {}), ("16 lanes", {"ACME_COOP_WAVE64": "0"}),
+                     ("literal", {"ACME_COOP_LITERAL": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = emu_runner(emu_lib, m, 3)
+        assert r.kernel_family() == ("generic" if tag == "lane per instance" else "coop")
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            y = r.run(u, check=False)
+        ra = r.report_arrays()
+        assert ra["first_nonfinite"].tolist() == [-1, 40, -1] and ra["n_warn"].tolist() == [0, 0, 0], tag
+        assert np.isnan(y[1, :, 40:]).all() and np.isfinite(y[1, :, :40]).all() and np.isfinite(y[[0, 2]]).all(), tag
+        got[tag] = (np.nan_to_num(y), ra["iters_total"].tolist())
+        for k in env:
+            monkeypatch.delenv(k)
+    for tag, (y, its) in got.items():
+        assert its == got["lane per instance"][1], tag
+        np.testing.assert_allclose(y, got["lane per instance"][0], rtol=1e-9, atol=1e-12)
