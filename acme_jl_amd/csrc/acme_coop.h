@@ -880,27 +880,20 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
         if (sl >= ks) own[sl] = wv::ld2(row[sl] + kc);
     });
     // which of the pairs right of the pivot's hold anything in the pivot row -- of ANY of the wave's instances: lane l looks
-    // at pairs l, l + 16 (, l + 32 beyond 62 columns: the right-hand side's pair of a 64-unknown system); one instance per
-    // wave: lane l at pair l
+    // at pairs l, l + 16 (, l + 32 beyond 62 columns: the right-hand side's pair of a 64-unknown system)
     const int g0 = kc / 2 + 1, g1 = n / 2;                // first and last pair of the update (g1: the right-hand side's)
+    static_assert(LPI == GROUP, "one instance per wave has a step of its own: coop_lu_w64_step");
     unsigned long long todo = 0ull;
-    if constexpr (LPI == 64) {
-        const int g = c.lig;
-        const bool in = g >= g0 && g <= g1;
-        const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
-        todo = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));          // (a NaN counts as something)
-    } else {
-        sfor<0, 3>([&](auto hc) ACME_LAMBDA {
-            constexpr int h = decltype(hc)::value;
-            if (h < 2 || g1 >= 32) {
-                const int g = c.lig + GROUP * h;
-                const bool in = g >= g0 && g <= g1;
-                const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
-                const unsigned long long bal = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));
-                todo |= ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << (GROUP * h);
-            }
-        });
-    }
+    sfor<0, 3>([&](auto hc) ACME_LAMBDA {
+        constexpr int h = decltype(hc)::value;
+        if (h < 2 || g1 >= 32) {
+            const int g = c.lig + GROUP * h;
+            const bool in = g >= g0 && g <= g1;
+            const wv::pair_t v = wv::ld2(prow + 2 * (in ? g : g1));
+            const unsigned long long bal = wv::ballot(in && !(v.lo == 0.0 && v.hi == 0.0));          // (a NaN counts as something)
+            todo |= ((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << (GROUP * h);
+        }
+    });
     // read ahead: the four pairs next to the pivot's and the right-hand side's, of the pivot row and of the rows below
     constexpr int NB = 4;
     wv::pair_t bb[NB + 1], ab[NS][NB + 1];
@@ -1135,13 +1128,14 @@ ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS]) {
                 wv::lds_order();
             }
         }
-    } else
-    for (int k = 0; k < n; k += 2) {
-        coop_lu_lds_step<NS, false, LPI>(c, n, k, vmx);
-        wv::lds_order();          // (a step reads what the step before wrote: the DS pipeline keeps a wave's program order)
-        if (k + 1 < n) {
-            coop_lu_lds_step<NS, true, LPI>(c, n, k + 1, vmx);
+    } else {
+        for (int k = 0; k < n; k += 2) {
+            coop_lu_lds_step<NS, false, LPI>(c, n, k, vmx);
             wv::lds_order();
+            if (k + 1 < n) {
+                coop_lu_lds_step<NS, true, LPI>(c, n, k + 1, vmx);
+                wv::lds_order();
+            }
         }
     }
 #ifdef ACME_COOP_TIMING
