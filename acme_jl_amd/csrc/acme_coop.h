@@ -966,11 +966,11 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
 // The same step for ONE INSTANCE PER WAVE (one row per lane), as ONE round trip through LDS where the matrix keeps its
 // pattern from one factorisation to the next -- it does: the pattern is the circuit's.  Beside the right-hand side's pair the
 // step reads AHEAD the pairs of columns this step's pivot row held LAST time (pred: a 64-bit mask per step, kept beside the
-// matrix, CoopOff::pm; up to six of them), of the pivot row and of the lane's own row -- and nothing else: with eight waves
+// matrix, CoopOff::pm; the first two of them), of the pivot row and of the lane's own row -- and nothing else: with eight waves
 // to a compute unit it is the LDS pipe the steps queue for (a 16-byte read of a wave takes it 4 cycles, a store 13), so a
 // pair that holds nothing is not read on the off chance.  Every load of the step is requested before the first is waited
 // for; whatever the pivot row holds that was not foreseen (a new row order, the first factorisation of a launch) takes the
-// slow way, a pair at a time, and is foreseen next time (seen).
+// same way afterwards, two pairs to a round trip, and is foreseen next time (seen).
 template <bool ODD>
 ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsigned long long pred, unsigned long long &seen) {
     double *F = c.W + c.O.llu;
@@ -984,7 +984,10 @@ ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsi
     const bool in = c.lig >= g0 && c.lig < g1;
     const wv::pair_t sv = wv::ld2(prow + 2 * (in ? c.lig : g1));          // lane l looks at pair l of the pivot row
     const wv::pair_t br = wv::ld2(prow + 2 * g1), ar = wv::ld2(row + 2 * g1);
-    constexpr int NF = 6;
+#ifndef ACME_W64_NF
+#define ACME_W64_NF 2          // (pairs read ahead per round trip: 1 / 2 / 3 / 4 / 6 / 8 measured, EXPERIMENTS.md -- a slot's mask arithmetic costs more than a round trip shared by the rare third pair saves)
+#endif
+    constexpr int NF = ACME_W64_NF;
     wv::pair_t bf[NF], af[NF];
     int gf[NF];
     // up to NF pairs of `from` requested (pivot row and own row); what was taken leaves `from`
@@ -1035,7 +1038,7 @@ ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsi
     };
     apply();
     COOP_T(c, CT_S_REST);
-    while (rest != 0ull) {          // what was not foreseen, or beyond the first six: NF pairs to a round trip
+    while (rest != 0ull) {          // what was not foreseen, or beyond the first NF: NF pairs to a round trip
 #ifdef ACME_COOP_TIMING
         c.tm->t[CT_S_CHUNKS] += 1;
 #endif
