@@ -67,7 +67,7 @@ struct CoopTimer { long long t[CT_N]; long long mark; };
 // 8.8 KB per instance at 20 unknowns instead of 15.9: 16 resident instances per compute unit instead of 8, a wave for
 // every SIMD.
 struct CoopOff {
-    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, dinv, pm, total;
+    int x, xn, z, lp, lz, ljp, llu, lsrc, p, pa, sp, zz, res, dz, lu, src, q, pf, tv, tmp, u, prow, xb, ld, dinv, total;
 };
 ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
     CoopOff o{};
@@ -88,10 +88,9 @@ ACME_HD inline CoopOff coop_offsets(const GenHeader &H, int nc) {
         // reads and writes: the right-hand side's partner is slack).  Every array at an even offset (16-byte accesses).
         auto take = [&](int n) { const int r = w; w += (n + 1) & ~1; return r; };
         o.ld = ((nn + 3) & ~3) + 2;                  // (>= nn + 2, and 2 mod 4 doubles: the 16 rows of a DPP row in 16 bank groups)
-        o.llu = take(nn * o.ld);
+        o.llu = take((nn + 1) * o.ld);               // (one row more: where the lanes beyond the matrix read and write when a wave holds ONE instance)
         o.xb = take(nn);                             // (behind the matrix: the replay's batched reads may run a few doubles past its last row)
         o.dinv = take(nn);
-        o.pm = take(nn);                             // (one instance per wave: which far pairs of columns each step's pivot row held last time)
         o.tv = take(4 * nn);
         // Jp by residual ROW, whatever position holds it: np columns and one that stays zero (where the padding entries of the
         // rows' sparse forms point, GenSub::o_pcol) -- or just the kp entries per row of the sparse form (GenHeader::jp_sparse)
@@ -965,19 +964,19 @@ ACME_DEV void coop_lu_lds_step(const CoopCtx &c, int n, int k, double &vmx) {
 }
 // The same step for ONE INSTANCE PER WAVE (one row per lane), as ONE round trip through LDS where the matrix keeps its
 // pattern from one factorisation to the next -- it does: the pattern is the circuit's.  Beside the right-hand side's pair the
-// step reads AHEAD the pairs of columns this step's pivot row held LAST time (pred: a 64-bit mask per step, kept beside the
-// matrix, CoopOff::pm; the first two of them), of the pivot row and of the lane's own row -- and nothing else: with eight waves
+// step reads AHEAD the pairs of columns this step's pivot row held LAST time (pred: a 64-bit mask per step, lane k keeps
+// step k's: CoopSolver::pm; the first two of them), of the pivot row and of the lane's own row -- and nothing else: with eight waves
 // to a compute unit it is the LDS pipe the steps queue for (a 16-byte read of a wave takes it 4 cycles, a store 13), so a
 // pair that holds nothing is not read on the off chance.  Every load of the step is requested before the first is waited
 // for; whatever the pivot row holds that was not foreseen (a new row order, the first factorisation of a launch) takes the
 // same way afterwards, two pairs to a round trip, and is foreseen next time (seen).
 template <bool ODD>
-ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsigned long long pred, unsigned long long &seen) {
+ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, unsigned long long &big, double &dinv, unsigned long long pred, unsigned long long &seen) {
     double *F = c.W + c.O.llu;
     const int ld = c.O.ld, kc = k & ~1;
     const double *prow = F + k * ld;
     const bool real = c.lig < n;
-    double *row = F + (real ? c.lig : n - 1) * ld;          // (a lane beyond the matrix reads its last row, writes nothing)
+    double *row = F + (real ? c.lig : n) * ld;          // (a lane beyond the matrix works on the spare row behind it: no predicates on the stores)
     const int g0 = kc / 2 + 1, g1 = n / 2;                // first and last pair of the update (g1: the right-hand side's)
     const bool rhs_apart = g0 <= g1;                      // (n odd, last step: the right-hand side shares the pivot's pair)
     const wv::pair_t pp = wv::ld2(prow + kc), own = wv::ld2(row + kc);
@@ -1013,25 +1012,23 @@ ACME_DEV void coop_lu_w64_step(const CoopCtx &c, int n, int k, double &vmx, unsi
     const double inv = wv::recip(piv);
     const bool below = real && c.lig > k;
     const double m = below ? -(ODD ? own.hi : own.lo) * inv : 0.0;
-    vmx = fmax(vmx, fabs(m));
-    if (c.lig == k) c.W[c.O.dinv + k] = inv;
+    big |= wv::ballot(fabs(m) > COOP_PIVOT_THRESHOLD);          // (the lanes whose multiplier trips the threshold, gathered over the steps)
+    dinv = c.lig == k ? inv : dinv;                              // (lane k keeps 1 / pivot of step k: to LDS once, behind the last step)
 #ifdef ACME_COOP_TIMING
     c.tm->t[CT_S_STEPS] += 1;
 #endif
     COOP_T(c, CT_S_BAND);
     if (wv::ballot(m != 0.0) == 0ull) return;          // (no row below holds anything in column k)
-    if (real) {
-        // column k of the rows below: minus the multiplier; the rows above (and the pivot's) keep what they hold
-        if (ODD) wv::st2(row + kc, own.lo, below ? m : own.hi);
-        else wv::st2(row + kc, below ? m : own.lo, fma(m, pp.hi, own.hi));
-        if (rhs_apart) wv::st2(row + 2 * g1, fma(m, br.lo, ar.lo), fma(m, br.hi, ar.hi));
-    }
+    // column k of the rows below: minus the multiplier; the rows above (and the pivot's) keep what they hold
+    if (ODD) wv::st2(row + kc, own.lo, below ? m : own.hi);
+    else wv::st2(row + kc, below ? m : own.lo, fma(m, pp.hi, own.hi));
+    if (rhs_apart) wv::st2(row + 2 * g1, fma(m, br.lo, ar.lo), fma(m, br.hi, ar.hi));
     // the requested pairs that the pivot row does hold are updated; `rest` keeps what is still to do
     auto apply = [&]() ACME_LAMBDA {
         sfor<0, NF>([&](auto ic) ACME_LAMBDA {
             constexpr int i = decltype(ic)::value;
             if (gf[i] >= 0 && ((rest >> gf[i]) & 1ull) != 0ull) {
-                if (real) wv::st2(row + 2 * gf[i], fma(m, bf[i].lo, af[i].lo), fma(m, bf[i].hi, af[i].hi));
+                wv::st2(row + 2 * gf[i], fma(m, bf[i].lo, af[i].lo), fma(m, bf[i].hi, af[i].hi));
                 rest &= ~(1ull << gf[i]);
             }
         });
@@ -1111,26 +1108,25 @@ template <int NS, int LPI> ACME_DEV void coop_lds_backward(int lig, int n, doubl
 // [J | res] of the matrix at O.llu -> its factorisation, x = J^-1 res (unknown p at position p).  Returns (per lane)
 // whether its instance must not trust the result: threshold tripped, zero or non-finite pivot.
 template <int NS, int LPI>
-ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS]) {
+ACME_DEV bool coop_lu_lds(const CoopCtx &c, int n, double (&x)[NS], unsigned long long &pm) {
     double vmx = 0.0;
     if constexpr (LPI == 64) {
-        // (the masks of foreseen pairs: step k's is requested a step ahead, rewritten where the step saw something else)
-        unsigned long long *Pm = reinterpret_cast<unsigned long long *>(c.W + c.O.pm);
-        unsigned long long nxt = Pm[0];
+        unsigned long long big = 0ull;
+        double dinv_k = 1.0;
         for (int k = 0; k < n; k += 2) {
-            unsigned long long pred = wv::first64(nxt), seen;
-            nxt = Pm[k + 1 < n ? k + 1 : k];
-            coop_lu_w64_step<false>(c, n, k, vmx, pred, seen);
-            if (seen != pred && c.lig == 0) Pm[k] = seen;
+            unsigned long long seen;
+            coop_lu_w64_step<false>(c, n, k, big, dinv_k, wv::lanev64(pm, k), seen);
+            pm = c.lig == k ? seen : pm;
             wv::lds_order();          // (a step reads what the step before wrote: the DS pipeline keeps a wave's program order)
             if (k + 1 < n) {
-                pred = wv::first64(nxt);
-                nxt = Pm[k + 2 < n ? k + 2 : k];
-                coop_lu_w64_step<true>(c, n, k + 1, vmx, pred, seen);
-                if (seen != pred && c.lig == 0) Pm[k + 1] = seen;
+                coop_lu_w64_step<true>(c, n, k + 1, big, dinv_k, wv::lanev64(pm, k + 1), seen);
+                pm = c.lig == k + 1 ? seen : pm;
                 wv::lds_order();
             }
         }
+        if (c.lig < n) c.W[c.O.dinv + c.lig] = dinv_k;
+        wv::lds_order();
+        vmx = big != 0ull ? 2.0 * COOP_PIVOT_THRESHOLD : 0.0;
     } else {
         for (int k = 0; k < n; k += 2) {
             coop_lu_lds_step<NS, false, LPI>(c, n, k, vmx);
@@ -1329,6 +1325,9 @@ struct CoopSolver {
     bool fresh;              // threshold path: the origin (lp, lz) has no recorded elimination yet (launch start): the next
                              // solve linearises there first.  Matrix in LDS: ... or its one matrix holds something else by now
     int rid4[COOP_SLOTS];    // threshold path on the matrix in LDS: the row each of the lane's (up to four) positions holds
+    unsigned long long pm;   // one instance per wave: lane k keeps which pairs of columns the pivot row of step k held last time
+                             // (coop_lu_w64_step reads them ahead): a register, read with v_readlane -- as a word in LDS it cost
+                             // every step a wait for the step before's stores
 };
 ACME_DEV void coop_accept_factors(CoopSolver &f, bool pred) {
     const int a = f.o_lu, b = f.o_src;
@@ -1446,7 +1445,7 @@ ACME_DEV void coop_linearize_lds(const CoopCtx &c, const GenSub &s, CoopSolver &
         });
         resmax = coop_allmax(c, rm);
         if (!finite) resmax = (double)NAN;
-        const bool trip = coop_lu_lds<NS, LPI>(c, nn, x);
+        const bool trip = coop_lu_lds<NS, LPI>(c, nn, x, f.pm);
         COOP_T(c, CT_LU);
         if (phase == 0) {
             learn = act && finite && trip;

@@ -425,6 +425,12 @@ template <int K> ACME_DEV double lane64(double v) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), K);
     return __hiloint2double(hi, lo);
 }
+// the 64-bit value lane `lane` (wave-uniform, a run-time number) of the wave holds, as a scalar
+ACME_DEV unsigned long long lanev64(unsigned long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
 // a 64-bit value every lane holds alike, as a wave-uniform (scalar) value: the first lane's
 ACME_DEV unsigned long long first64(unsigned long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);

@@ -257,6 +257,7 @@ ACME_DEV double allmin16(double v) {
     v = fmin(v, ror16<1>(v));
     return v;
 }
+ACME_DEV unsigned long long lanev64(unsigned long long v, int lane) { return emu::exchange(v, lane & 63, 701); }
 ACME_DEV unsigned long long first64(unsigned long long v) { return v; }          // (every lane holds it alike)
 template <int K> ACME_DEV double lane64(double v) { return emu::u2d(emu::exchange(emu::d2u(v), K, 600 + K)); }
 ACME_DEV double allmax64(double v) {
