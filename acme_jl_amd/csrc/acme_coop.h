@@ -241,16 +241,20 @@ ACME_DEV double coop_dot_diff(const double *a, int sa, const double *b, const do
 // acc + (row r of a matrix in its sparse form, GenEll) * x: the non-zeros in ascending column order -- the dense loop's
 // multiply-adds without the ones that add 0 * x_j
 ACME_DEV double coop_ell_dot(const double *M, const GenEll &E, int r, const double *x, double acc) {
-    for (int e = 0; e < E.k; e += 4) {
-        double v[4], xv[4];
-        int ci[4];
-        for (int u = 0; u < 4; ++u) {
+#ifndef ACME_ELL_BATCH
+#define ACME_ELL_BATCH 2          // (entries requested together: a circuit's rows hold one to three)
+#endif
+    constexpr int B = ACME_ELL_BATCH;
+    for (int e = 0; e < E.k; e += B) {
+        double v[B], xv[B];
+        int ci[B];
+        for (int u = 0; u < B; ++u) {
             const int ee = e + u < E.k ? e + u : E.k - 1;
             v[u] = M[E.o_val + ee * E.rows + r];
             ci[u] = (int)M[E.o_col + ee * E.rows + r];
         }
-        for (int u = 0; u < 4; ++u) xv[u] = x[ci[u]];
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < B; ++u) xv[u] = x[ci[u]];
+        for (int u = 0; u < B; ++u)
             if (e + u < E.k) acc = fma(v[u], xv[u], acc);
     }
     return acc;
@@ -1197,15 +1201,19 @@ ACME_DEV bool coop_evaluate_lds(const CoopCtx &c, const GenSub &s, int w_z, cons
             if (c.ell) {
                 // J row = Jq row * fq from the row's sparse form (GenSub::o_jcol): zeros, then the columns that hold anything
                 for (int j = 0; j < c.O.ld; j += 2) wv::st2(row + j, 0.0, 0.0);
-                for (int e = 0; e < s.kj; e += 4) {
-                    int col[4];
-                    double cf[4][4];
-                    for (int u = 0; u < 4; ++u) {
+#ifndef ACME_JROW_BATCH
+#define ACME_JROW_BATCH 4          // (entries of a row's sparse form requested together)
+#endif
+                constexpr int JB = ACME_JROW_BATCH;
+                for (int e = 0; e < s.kj; e += JB) {
+                    int col[JB];
+                    double cf[JB][4];
+                    for (int u = 0; u < JB; ++u) {
                         const int ee = e + u < s.kj ? e + u : s.kj - 1;
                         col[u] = (int)c.M[s.o_jcol + ee * s.nn + r];
                         for (int t = 0; t < 4; ++t) cf[u][t] = c.M[s.o_jcoef + (ee * 4 + t) * s.nn + r];
                     }
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < JB; ++u) {
                         double acc = 0.0;
                         for (int t = 0; t < 4; ++t) acc = fma(tv[t], cf[u][t], acc);
                         bad = bad || !(acc * 0.0 == 0.0);
