@@ -165,12 +165,17 @@ ACME_HD inline int coop_cache_doubles(const GenHeader &H) { return H.nsub > 0 ? 
 ACME_HD inline int coop_inst_doubles(const GenHeader &H, int nc) { return ((coop_offsets(H, nc).total + 1) & ~1) + coop_cache_doubles(H); }
 // what a block stages of a shared model image: all of it -- or, for the instantiations on a matrix in LDS when the image has
 // its sparse forms (GenHeader::ell), only those: they read nothing else
-// (the register instantiations and the literal one read the dense matrices -- from an image in LDS one round trip per
-// batch of operands, where the sparse forms take two: the column numbers first -- and stage only those)
-ACME_HD inline bool coop_reads_sparse(const GenHeader &H, int nc) { return nc < 0 && H.ell != 0; }
-ACME_HD inline int coop_image_first(const GenHeader &H, int nc) { return coop_reads_sparse(H, nc) ? H.o_ell : 0; }
+// Who reads what of the image.  The instantiations on a matrix in LDS: the sparse forms only (and stage only those).  The
+// register instantiations: the matrices' sparse forms for the matrix-vector products (q, p, x / y: two or three multiply-adds
+// instead of a dense row's twenty) and the DENSE fq / pexp for the rows of J and Jp, which they assemble in registers with
+// compile-time column numbers -- they stage everything but the rows' tables at the image's end (GenHeader::reg_sparse: where
+// that costs no resident instance -- 20 unknowns + 12 %, 32 + 4 %; at 24 it would cost one).  The literal one: the dense
+// matrices, as the lane-per-instance kernel it is bit-identical to.
+ACME_HD inline bool coop_reads_sparse(const GenHeader &H, int nc) { return (nc < 0 || (nc > 0 && H.reg_sparse != 0)) && H.ell != 0; }
+ACME_HD inline int coop_image_first(const GenHeader &H, int nc) { return nc < 0 && H.ell != 0 ? H.o_ell : 0; }
 ACME_HD inline int coop_image_doubles(const GenHeader &H, int nc) {
-    return ((coop_reads_sparse(H, nc) ? H.image_total : H.o_ell) - coop_image_first(H, nc) + 1) & ~1;
+    const int end = nc < 0 && H.ell != 0 ? H.image_total : coop_reads_sparse(H, nc) ? H.o_jtab : H.o_ell;
+    return (end - coop_image_first(H, nc) + 1) & ~1;
 }
 ACME_HD inline int coop_shared_doubles(const GenHeader &H, bool shared_image, int nc) {
     return (shared_image ? coop_image_doubles(H, nc) : 0) + coop_table_doubles(H);

@@ -52,6 +52,9 @@ struct GenHeader {
     int ell;                 // the sparse forms below and in sub[0] exist and hold every non-zero of this model (a batch: of every
                              // instance's model) -- the mid-size kernel reads them instead of the dense matrices
     int o_ell;               // where the sparse part of the image begins (an even offset; image_total if there is none)
+    int o_jtab;              // ... and, inside it, where the rows of J and Jp begin (behind the matrices' own sparse forms)
+    int reg_sparse;          // the mid-size kernel's REGISTER instantiations read the matrices' sparse forms for their matrix-vector
+                             // products (set by the host where staging them beside the dense matrices costs no resident instance)
     int jp_sparse;           // the mid-size kernel on a matrix in LDS keeps Jp as the kp entries per row of its sparse form, not as
                              // np columns (set by the host for a batch that shares ONE model image: its sparse forms cannot change)
     GenEll e_ax, e_bu, e_cz; // [a; dy], [b; ey], [c; fy]: the nx state rows followed by the ny output rows

@@ -712,7 +712,7 @@ inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err,
     H.has_bjt = dummy.has_bjt;
     // ---- the sparse forms of the matrices (the mid-size kernel, acme_coop.h: one sub-problem or none), behind the dense ones ----
     H.ell = 0;
-    H.o_ell = H.image_total;
+    H.o_ell = H.o_jtab = H.image_total;
     if (H.nsub <= 1) {
         const int base = (H.image_total + 1) & ~1;
         std::vector<double> tail;
@@ -789,9 +789,11 @@ inline bool pack_generic(const HostModel &m, PackedGeneric &G, std::string &err,
                     }
                 }
             };
+            H.o_jtab = at();
             rows_of(s.fq, s.nn, s.nn + 1, lg ? lg->kj : -1, g.kj, g.o_jcol, g.o_jcoef);
             rows_of(s.pexp, s.np, s.np, lg ? lg->kp : -1, g.kp, g.o_pcol, g.o_pcoef);
         }
+        if (H.nsub != 1) H.o_jtab = at();
         H.o_ell = base;
         H.ell = fits ? 1 : 0;
         G.image.resize((size_t)base, 0.0);
